@@ -1,0 +1,122 @@
+"""ctypes binding of libast_hip.so (include/ast_hip.h).
+
+The product path has NO fallback: importing an op without the built library, or
+calling one without a GPU, raises.  Build with `python __graft_entry__.py` (or
+`make -C audio-style-transfer_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libast_hip.so")
+
+F32, BF16 = 0, 1
+MAX_TAPS = 9
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class Gather(C.Structure):
+    """ast_gather_t"""
+    _fields_ = [(n, i32) for n in ("N", "Hs", "Ws", "Cs", "Hm", "Wm", "sh", "sw", "oh", "ow", "Hd", "Wd", "Cd",
+                                   "dsh", "dsw", "doh", "dow", "ntaps", "wtaps")] + [("tap", i32 * MAX_TAPS)]
+
+
+class WeightDesc(C.Structure):
+    """ast_weight_desc_t"""
+    _fields_ = [("w", vp), ("u", vp), ("v", vp), ("sigma", vp), ("scratch", vp), ("wf", vp), ("wb", vp)] + \
+               [(n, i32) for n in ("Co", "Ci", "KK", "s_co", "s_ci", "Cop", "Cip", "power_iter")]
+
+
+_SIGS = {
+    "ast_version": ([], i32),
+    "ast_igemm": ([vp, vp, vp, vp, C.POINTER(Gather), i32, i32, vp], i32),
+    "ast_wgrad": ([vp, vp, vp, C.POINTER(Gather), i32, vp], i32),
+    "ast_nchw_to_nhwc": ([vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, i32, vp], i32),
+    "ast_nhwc_to_nchw": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "ast_cast": ([vp, i32, vp, i32, i64, vp], i32),
+    "ast_weights_prepare_v": ([vp, vp, i32, i32, i32, C.c_long, vp], i32),
+    "ast_weight_grad_unpack": ([vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp], i32),
+    "ast_chan_stats": ([vp, vp, i32, i32, i32, i32, vp], i32),
+    "ast_norm_finalize": ([vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp, vp, vp, vp], i32),
+    "ast_affine_act": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "ast_norm_bwd_sums": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "ast_norm_bwd_finalize": ([vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
+    "ast_norm_bwd_apply": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "ast_layernorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp], i32),
+    "ast_layernorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),
+    "ast_adaptive_pool_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "ast_adaptive_pool_bwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "ast_bilinear_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "ast_bilinear_bwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "ast_attn_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp], i32),
+    "ast_attn_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp], i32),
+    "ast_add": ([vp, vp, vp, i64, i32, vp], i32),
+    "ast_relu_bwd": ([vp, vp, vp, i64, i32, vp], i32),
+    "ast_dropout_mask": ([vp, i64, f32, C.c_uint64, vp, vp], i32),
+    "ast_mul": ([vp, vp, vp, i64, i32, vp], i32),
+    "ast_recon_loss": ([vp, vp, i64, i32, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp], i32),
+    "ast_infonce": ([vp, vp, i32, i32, f32, vp, vp, vp, vp], i32),
+    "ast_margin": ([vp, i32, i32, f32, vp, vp, vp], i32),
+    "ast_hsic": ([vp, vp, i32, i32, vp, vp, vp, vp, vp], i32),
+    "ast_cross_entropy": ([vp, vp, i32, i32, vp, vp, vp], i32),
+    "ast_softmax_entropy": ([vp, i32, i32, vp, vp, vp], i32),
+    "ast_scale": ([vp, vp, f32, vp, i64, i32, vp], i32),
+    "ast_colsum_acc": ([vp, i64, i32, i32, vp, i32, vp], i32),
+    "ast_sumsq": ([vp, i64, vp, vp], i32),
+    "ast_adam": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp, f32, vp], i32),
+    "ast_counter_incr": ([vp, vp], i32),
+    "ast_stft_sections": ([vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp], i32),
+}
+
+EXPORTS = tuple(_SIGS) + ("ast_last_error",)
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP library has not been built (run `python __graft_entry__.py` "
+                "or `make -C audio-style-transfer_amd/csrc`). There is no CPU/PyTorch fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes, fn.restype = args, res
+        L.ast_last_error.argtypes, L.ast_last_error.restype = [], C.c_char_p
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise RuntimeError(f"libast_hip {what} failed ({rc}): {lib().ast_last_error().decode()}")
+
+
+def dcode(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported activation dtype {dtype}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: the
+    kernels would fault on them."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libast_hip needs device tensors (got a CPU tensor); there is no CPU path")
+    return t.data_ptr()

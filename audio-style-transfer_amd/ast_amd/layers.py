@@ -1,0 +1,193 @@
+"""Host-side building blocks shared by the drop-in modules.
+
+torch.nn classes (Conv2d+spectral_norm, BatchNorm2d, Linear, MultiheadAttention,
+Transformer*Layer ...) are used ONLY as parameter containers, so construction,
+default initialisation, ``state_dict`` keys/shapes and checkpoint loading are
+identical to the reference by construction; their ``forward`` is never called --
+all arithmetic goes through libast_hip (ops.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import config, ops
+from ._lib import WeightDesc, check, dcode, lib, ptr, stream
+from .ops import PackedWeight, pad8
+
+
+class WeightBank:
+    """All GEMM weights of one model.  ``prepare(training)`` runs, in three
+    launches for the whole model, the spectral-norm power iteration
+    (torch spectral_norm.py:92-114), sigma, and the packing of W/sigma into the
+    [rows][tap][channel] images the MFMA kernels read."""
+
+    def __init__(self):
+        self.specs = []
+        self.entries: list[PackedWeight] = []
+        self._key = None
+
+    def add(self, weight, kind, dtype_fn, u=None, v=None, bias=None, rows=None):
+        """kind: 'conv' (Co,Ci,k,k) | 'convT' (Ci,Co,k,k) | 'linear' (Co,Ci); rows=(r0,r1) selects output rows
+        of a linear weight (packed q/k/v projections).  dtype_fn() gives the packed dtype at build time."""
+        self.specs.append((weight, kind, dtype_fn, u, v, bias, rows))
+        self.entries.append(PackedWeight())
+        return self.entries[-1]
+
+    def _signature(self):
+        return tuple((w.data_ptr(), w.device, fn()) for w, _, fn, *_ in self.specs)
+
+    def _build(self):
+        dev = self.specs[0][0].device
+        descs_t, descs_e, dts = [], [], []
+        self.max_co = self.max_cols = self.max_packed = 1
+        for e, (w, kind, dtype_fn, u, v, bias, rows) in zip(self.entries, self.specs):
+            dt = dtype_fn()
+            if kind == "conv":
+                Co, Ci, k, _ = w.shape
+                KK, s_co, s_ci, w_off, b_off = k * k, Ci * k * k, k * k, 0, 0
+            elif kind == "convT":
+                Ci, Co, k, _ = w.shape
+                KK, s_co, s_ci, w_off, b_off = k * k, k * k, Co * k * k, 0, 0
+            else:
+                Co, Ci = w.shape
+                r0, r1 = rows if rows else (0, Co)
+                Co, KK, s_co, s_ci, w_off, b_off = r1 - r0, 1, Ci, 1, r0 * Ci, r0
+            e.weight, e.u, e.v, e.bias = w, u, v, bias
+            e.Co, e.Ci, e.KK, e.s_co, e.s_ci, e.w_off, e.b_off = Co, Ci, KK, s_co, s_ci, w_off, b_off
+            e.Cop, e.Cip, e.dtype = pad8(Co), pad8(Ci), dt
+            n = e.Cop * KK * e.Cip
+            e.wf = torch.empty(n, dtype=dt, device=dev)
+            e.wb = torch.empty(n, dtype=dt, device=dev)
+            e.sigma = torch.ones(1, dtype=torch.float32, device=dev)
+            e.scratch = torch.zeros(Co + Ci * KK, dtype=torch.float32, device=dev)
+            e.gtmp = torch.zeros(1, dtype=torch.float32, device=dev)
+            e.bias_pad = torch.zeros(e.Cop, dtype=torch.float32, device=dev) if (bias is not None and Co != e.Cop) else None
+            for power, lst in ((1, descs_t), (0, descs_e)):
+                lst.append(WeightDesc(w=w.data_ptr() + 4 * w_off, u=ptr(u), v=ptr(v), sigma=ptr(e.sigma),
+                                      scratch=ptr(e.scratch), wf=ptr(e.wf), wb=ptr(e.wb), Co=Co, Ci=Ci, KK=KK, s_co=s_co,
+                                      s_ci=s_ci, Cop=e.Cop, Cip=e.Cip, power_iter=power))
+            dts.append(dcode(dt))
+            self.max_co = max(self.max_co, Co)
+            self.max_cols = max(self.max_cols, Ci * KK)
+            self.max_packed = max(self.max_packed, n)
+
+        def to_dev(lst):
+            arr = (WeightDesc * len(lst))(*lst)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            return host.to(dev)
+
+        self.d_train, self.d_eval = to_dev(descs_t), to_dev(descs_e)
+        self.d_dtypes = torch.tensor(dts, dtype=torch.int32, device=dev)
+        self._key = self._signature()
+
+    def prepare(self, training: bool):
+        if self._key != self._signature():
+            self._build()
+        d = self.d_train if training else self.d_eval
+        check(lib().ast_weights_prepare_v(ptr(d), ptr(self.d_dtypes), len(self.entries), self.max_co, self.max_cols,
+                                          self.max_packed, stream()), "ast_weights_prepare_v")
+
+
+def img_dtype():
+    return config.compute_dtype
+
+
+def tok_dtype():
+    return torch.float32
+
+
+# ---- thin functional wrappers --------------------------------------------------------
+def conv(x, pw, k, stride, pad, bias_grad):
+    return ops.Conv2dFn.apply(x, pw.weight, pw, k, stride, pad, bias_grad)
+
+
+def convT(x, pw, k, stride, pad, out_pad, bias_grad):
+    return ops.ConvT2dFn.apply(x, pw.weight, pw, k, stride, pad, out_pad, bias_grad)
+
+
+def linear(x2d, pw, relu=False):
+    y = ops.LinearFn.apply(x2d, pw.weight, pw, relu)
+    return y if pw.Cop == pw.Co else y[:, :pw.Co]
+
+
+def bn_act(x, bn: nn.BatchNorm2d, training, relu=True):
+    return ops.BatchNormActFn.apply(x, bn.weight, bn.bias, bn, training, relu)
+
+
+def layer_norm(x, ln: nn.LayerNorm):
+    return ops.LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)
+
+
+class MHA:
+    """Bank entries + forward for one nn.MultiheadAttention container."""
+
+    def __init__(self, bank: WeightBank, m: nn.MultiheadAttention, cross: bool):
+        d = m.embed_dim
+        self.m, self.d, self.h, self.cross = m, d, m.num_heads, cross
+        if cross:
+            self.q = bank.add(m.in_proj_weight, "linear", tok_dtype, bias=m.in_proj_bias, rows=(0, d))
+            self.kv = bank.add(m.in_proj_weight, "linear", tok_dtype, bias=m.in_proj_bias, rows=(d, 3 * d))
+        else:
+            self.qkv = bank.add(m.in_proj_weight, "linear", tok_dtype, bias=m.in_proj_bias)
+        self.out = bank.add(m.out_proj.weight, "linear", tok_dtype, bias=m.out_proj.bias)
+
+    def __call__(self, x, mem, training, p_drop, causal=False):
+        """x: (B,Lq,d), mem: (B,Lk,d) or None for self-attention."""
+        B, Lq, d = x.shape
+        dh = d // self.h
+        if self.cross:
+            Lk = mem.shape[1]
+            q = linear(x.reshape(B * Lq, d), self.q)
+            kv = linear(mem.reshape(B * Lk, d), self.kv)
+            k_off, v_off = 0, d
+        else:
+            Lk = Lq
+            q = kv = linear(x.reshape(B * Lq, d), self.qkv)
+            k_off, v_off = d, 2 * d
+        mask = ops.dropout_mask((B, self.h, Lq, Lk), p_drop, x.device) if (training and p_drop > 0) else None
+        o = ops.AttnCoreFn.apply(q, kv, B, self.h, Lq, Lk, dh, k_off, v_off, causal, mask)
+        return linear(o, self.out).view(B, Lq, d)
+
+
+class EncoderLayer:
+    """nn.TransformerEncoderLayer defaults: post-norm, ReLU FFN (style_encoder.py:181-187)."""
+
+    def __init__(self, bank, layer: nn.TransformerEncoderLayer):
+        self.l = layer
+        self.attn = MHA(bank, layer.self_attn, cross=False)
+        self.ff1 = bank.add(layer.linear1.weight, "linear", tok_dtype, bias=layer.linear1.bias)
+        self.ff2 = bank.add(layer.linear2.weight, "linear", tok_dtype, bias=layer.linear2.bias)
+
+    def __call__(self, x, training):
+        l, p = self.l, self.l.dropout.p
+        B, L, d = x.shape
+        x = layer_norm(x + ops.dropout(self.attn(x, None, training, l.self_attn.dropout), l.dropout1.p, training), l.norm1)
+        h = ops.dropout(linear(x.reshape(B * L, d), self.ff1, relu=True), p, training)
+        h = ops.dropout(linear(h, self.ff2), l.dropout2.p, training).view(B, L, d)
+        return layer_norm(x + h, l.norm2)
+
+
+class DecoderLayer:
+    """nn.TransformerDecoderLayer(norm_first=True) (new_decoder.py:111-118)."""
+
+    def __init__(self, bank, layer: nn.TransformerDecoderLayer):
+        self.l = layer
+        self.sa = MHA(bank, layer.self_attn, cross=False)
+        self.ca = MHA(bank, layer.multihead_attn, cross=True)
+        self.ff1 = bank.add(layer.linear1.weight, "linear", tok_dtype, bias=layer.linear1.bias)
+        self.ff2 = bank.add(layer.linear2.weight, "linear", tok_dtype, bias=layer.linear2.bias)
+
+    def __call__(self, x, memory, training):
+        l = self.l
+        B, L, d = x.shape
+        h = layer_norm(x, l.norm1)
+        x = x + ops.dropout(self.sa(h, None, training, l.self_attn.dropout, causal=True), l.dropout1.p, training)
+        h = layer_norm(x, l.norm2)
+        x = x + ops.dropout(self.ca(h, memory, training, l.multihead_attn.dropout), l.dropout2.p, training)
+        h = layer_norm(x, l.norm3)
+        h = ops.dropout(linear(h.reshape(B * L, d), self.ff1, relu=True), l.dropout.p, training)
+        h = ops.dropout(linear(h, self.ff2), l.dropout3.p, training).view(B, L, d)
+        return x + h

@@ -1,0 +1,101 @@
+"""Drop-in for the torch-only part of the reference's utilityFunctions.py on libast_hip.
+
+get_STFT runs the LDS-staged radix-4 FFT kernel; get_overlap_windows /
+sections2spectrogram / concat_stft_cqt are index plumbing on device tensors.
+get_CQT / inverse_CQT (librosa arithmetic, parity unpinned) and load_audio
+(torchaudio decode) are not provided in this round.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import check, lib, ptr, stream
+
+WINDOW_SIZE = 287
+OVERLAP_PERCENTAGE = 0.3
+OVERLAP_FRAMES = 96
+
+
+def _ident_stats(device):
+    return torch.zeros(2, 513, device=device), torch.ones(2, 513, device=device) - 1e-8
+
+
+def stft_sections(waves: torch.Tensor, mean=None, std=None, n_sections=None, F_total=513, out=None):
+    """waves (Bc, n) f32 cuda -> (Bc, S, 2, 287, F_total): STFT + z-score + windowing in one kernel
+    (utilityFunctions.py:12-37,240-263; dataloader.py:9-13).  Bins >= 513 are left untouched."""
+    Bc, n = waves.shape
+    T = 1 + n // 256
+    step = WINDOW_SIZE - OVERLAP_FRAMES
+    if n_sections is None:
+        n_sections = len(section_starts(T))
+    if mean is None:
+        mean, std = _ident_stats(waves.device)
+    if out is None:
+        out = torch.zeros((Bc, n_sections, 2, WINDOW_SIZE, F_total), dtype=torch.float32, device=waves.device)
+    check(lib().ast_stft_sections(ptr(waves.contiguous()), Bc, n, ptr(mean.contiguous()), ptr(std.contiguous()), ptr(out),
+                                  n_sections, WINDOW_SIZE, step, F_total, stream()), "ast_stft_sections")
+    return out
+
+
+def section_starts(n_time, window_size=WINDOW_SIZE, overlap_frames=OVERLAP_FRAMES):
+    step, starts = window_size - overlap_frames, []
+    for s in range(0, n_time, step):
+        e = min(s + window_size, n_time)
+        if e - s < window_size * 0.5:
+            break
+        starts.append(s)
+        if e == n_time:
+            break
+    return starts
+
+
+def get_STFT(waveform, n_fft=1024, hop_length=256):
+    """utilityFunctions.py:12-37: (channels, samples) or (samples,) -> (2, T, 513)."""
+    if n_fft != 1024 or hop_length != 256:
+        raise NotImplementedError("the HIP front-end is built for n_fft=1024, hop=256 (the reference's only configuration)")
+    w = waveform.reshape(1, -1).float()
+    n = w.shape[1]
+    T = 1 + n // 256
+    # one "section" of T rows, step irrelevant: reuse the section kernel with win = T
+    mean, std = _ident_stats(w.device)
+    out = torch.empty((1, 1, 2, T, 513), dtype=torch.float32, device=w.device)
+    check(lib().ast_stft_sections(ptr(w.contiguous()), 1, n, ptr(mean), ptr(std), ptr(out), 1, T, T, 513, stream()),
+          "ast_stft_sections")
+    return out[0, 0]
+
+
+def get_overlap_windows(spectrogram, window_size=WINDOW_SIZE, overlap_frames=OVERLAP_FRAMES):
+    """utilityFunctions.py:240-263: (2,T,F) -> (S,2,window,F); tails shorter than half a window are dropped."""
+    Cc, n_time, n_freq = spectrogram.shape
+    starts = section_starts(n_time, window_size, overlap_frames)
+    out = spectrogram.new_zeros((len(starts), Cc, window_size, n_freq))
+    for i, s in enumerate(starts):
+        e = min(s + window_size, n_time)
+        out[i, :, :e - s] = spectrogram[:, s:e]
+    return out
+
+
+def sections2spectrogram(sections, original_size, overlap=OVERLAP_FRAMES):
+    """utilityFunctions.py:265-283: overlap-average."""
+    n_sections, _, wind, n_freq = sections.shape
+    hop = wind - overlap
+    n_time = hop * (n_sections - 1) + wind
+    full = sections.new_zeros((2, n_time, n_freq))
+    count = sections.new_zeros((1, n_time, 1))
+    for i in range(n_sections):
+        full[:, i * hop:i * hop + wind] += sections[i]
+        count[:, i * hop:i * hop + wind] += 1.0
+    return (full / count.clamp(min=1.0))[:, :original_size]
+
+
+def concat_stft_cqt(stft, cqt):
+    """utilityFunctions.py:285-299."""
+    if stft.ndim != 3 or cqt.ndim != 3:
+        raise ValueError(f"Both tensors must be 3D, got {stft.ndim}D e {cqt.ndim}D.")
+    if stft.shape[0] != cqt.shape[0] or stft.shape[1] != cqt.shape[1]:
+        raise ValueError(f"Channel/Time mismatch: stft {stft.shape[:2]} vs cqt {cqt.shape[:2]}")
+    return torch.cat([stft, cqt], dim=2)
+
+
+def get_CQT(*a, **k):
+    raise NotImplementedError("get_CQT: librosa's CQT is parity-unpinned (no librosa in any build/run image); not built in this round")

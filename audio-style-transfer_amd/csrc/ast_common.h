@@ -1,0 +1,82 @@
+// Shared device/host helpers for libast_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+enum { AST_F32 = 0, AST_BF16 = 1 };
+
+// ---- error plumbing: C-ABI returns 0 / negative, message via ast_last_error()
+void ast_set_error(const char* fmt, ...);
+#define AST_FAIL(...) do { ast_set_error(__VA_ARGS__); return -1; } while (0)
+#define AST_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) { ast_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return -2; } } while (0)
+#define AST_HIP(x) do { hipError_t e_ = (x); \
+    if (e_ != hipSuccess) { ast_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return -3; } } while (0)
+
+// ---- 8-channel unit load/store (NHWC tensors keep C a multiple of 8)
+template <typename T> struct U8;
+template <> struct U8<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+  }
+};
+template <> struct U8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x = multiple of 64 (<= 1024); all threads get the result
+__device__ __forceinline__ float block_sum(float v, float* red /* >= 17 floats of LDS */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < nw; ++i) s += red[i]; red[16] = s; }
+  __syncthreads();
+  return red[16];
+}
+
+#define AST_DISPATCH_T(dtype, ...) \
+  do { if ((dtype) == AST_F32) { using T = float; __VA_ARGS__; } \
+       else if ((dtype) == AST_BF16) { using T = bf16_t; __VA_ARGS__; } \
+       else AST_FAIL("%s: bad dtype %d", __func__, (int)(dtype)); } while (0)

@@ -1,0 +1,78 @@
+// STFT front-end (utilityFunctions.py:12-37): 1024-point Hann-windowed frames,
+// hop 256, reflect padding, as an LDS-staged radix-4 Stockham FFT -- one
+// 256-thread workgroup per frame, one radix-4 butterfly per thread per stage
+// (5 stages).  The epilogue z-scores each bin (dataloader.py:9-13) and writes the
+// frame straight into its row of the (B,S,2,287,F) section tensor
+// (utilityFunctions.py:240-263), so the spectrogram never exists in HBM in
+// (freq,time) order and no separate normalise / window / collate pass runs.
+#include "ast_common.h"
+#include "../../include/ast_hip.h"
+
+namespace {
+constexpr int NFFT = 1024, HOP = 256, NBIN = 513;
+
+__global__ __launch_bounds__(256) void stft_sections_kernel(const float* __restrict__ wave, int nsamp, int T, const float* __restrict__ mean,
+                                                             const float* __restrict__ stdv, float* __restrict__ x, int S, int win, int step,
+                                                             int Ftot) {
+  __shared__ float2 buf[2][NFFT];
+  const int row = blockIdx.x, s = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int t = s * step + row;
+  float* xr = x + ((((size_t)b * S + s) * 2 + 0) * win + row) * Ftot;
+  float* xi = x + ((((size_t)b * S + s) * 2 + 1) * win + row) * Ftot;
+  if (t >= T) {            // zero padded tail rows of the last section
+    for (int f = tid; f < NBIN; f += 256) { xr[f] = 0.f; xi[f] = 0.f; }
+    return;
+  }
+  const float* w = wave + (size_t)b * nsamp;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = tid + 256 * k;
+    int idx = t * HOP + j - NFFT / 2;
+    if (idx < 0) idx = -idx;
+    if (idx >= nsamp) idx = 2 * (nsamp - 1) - idx;
+    const float hann = 0.5f - 0.5f * cospif(2.f * j / NFFT);
+    buf[0][j] = make_float2(w[idx] * hann, 0.f);
+  }
+  __syncthreads();
+  int cur = 0;
+#pragma unroll
+  for (int p = 1; p < NFFT; p *= 4) {
+    const int k = tid & (p - 1);
+    const int j = ((tid - k) << 2) + k;
+    const float alpha = -(float)k / (2.f * p);          // in units of pi
+    float s1, c1, s2, c2, s3, c3;
+    sincospif(alpha, &s1, &c1); sincospif(2.f * alpha, &s2, &c2); sincospif(3.f * alpha, &s3, &c3);
+    const float2 a0 = buf[cur][tid], a1 = buf[cur][tid + 256], a2 = buf[cur][tid + 512], a3 = buf[cur][tid + 768];
+    const float2 u0 = a0;
+    const float2 u1 = make_float2(a1.x * c1 - a1.y * s1, a1.x * s1 + a1.y * c1);
+    const float2 u2 = make_float2(a2.x * c2 - a2.y * s2, a2.x * s2 + a2.y * c2);
+    const float2 u3 = make_float2(a3.x * c3 - a3.y * s3, a3.x * s3 + a3.y * c3);
+    const float2 v0 = make_float2(u0.x + u2.x, u0.y + u2.y), v1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+    const float2 v2 = make_float2(u1.x + u3.x, u1.y + u3.y);
+    const float2 d = make_float2(u1.x - u3.x, u1.y - u3.y);
+    const float2 v3 = make_float2(d.y, -d.x);            // -i * (u1 - u3)
+    buf[cur ^ 1][j] = make_float2(v0.x + v2.x, v0.y + v2.y);
+    buf[cur ^ 1][j + p] = make_float2(v1.x + v3.x, v1.y + v3.y);
+    buf[cur ^ 1][j + 2 * p] = make_float2(v0.x - v2.x, v0.y - v2.y);
+    buf[cur ^ 1][j + 3 * p] = make_float2(v1.x - v3.x, v1.y - v3.y);
+    cur ^= 1;
+    __syncthreads();
+  }
+  for (int f = tid; f < NBIN; f += 256) {
+    const float2 z = buf[cur][f];
+    xr[f] = (z.x - mean[f]) / (stdv[f] + 1e-8f);
+    xi[f] = (z.y - mean[NBIN + f]) / (stdv[NBIN + f] + 1e-8f);
+  }
+}
+}  // namespace
+
+extern "C" int ast_stft_sections(const float* wave, int Bc, int nsamp, const float* mean, const float* std_, float* x, int S, int win,
+                                 int step, int F_total, void* stream) {
+  if (!wave || !mean || !std_ || !x || Bc <= 0 || nsamp <= NFFT / 2 || S <= 0 || win <= 0 || step <= 0 || F_total < NBIN)
+    AST_FAIL("ast_stft_sections: bad args");
+  const int T = 1 + nsamp / HOP;
+  hipLaunchKernelGGL(stft_sections_kernel, dim3(win, S, Bc), dim3(256), 0, (hipStream_t)stream, wave, nsamp, T, mean, std_, x, S, win, step,
+                     F_total);
+  AST_CHECK_LAUNCH();
+  return 0;
+}

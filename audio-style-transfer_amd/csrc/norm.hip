@@ -1,0 +1,368 @@
+// Per-channel statistics and fused normalise/activation passes over NHWC
+// activations (HBM-bound streaming kernels; 16-32 B per lane, f32 math).
+//   BatchNorm2d (training): conv -> chan_stats -> norm_finalize -> affine_act
+//   ResBlock tail: relu(BN(c2) + IN(ds)) is ONE affine_act pass over two inputs
+//   backward: norm_bwd_sums -> norm_bwd_finalize -> norm_bwd_apply (one reduce
+//   pass + one elementwise pass for both branches together)
+#include "ast_common.h"
+#include "../../include/ast_hip.h"
+
+namespace {
+
+// ---- reductions over pixels: sums[n][c][K] -------------------------------------
+// MODE 0: {x, x^2}           (K=2)   inputs: a=x
+// MODE 1: {dz, dz*x, dz*r}   (K=3)   inputs: a=dy, b=y (relu mask), c=x, d=r (may be null)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                           const T* __restrict__ c, const T* __restrict__ d,
+                                                           float* __restrict__ sums, int HW, int C, int ppb, int relu) {
+  constexpr int K = MODE == 0 ? 2 : 3;
+  __shared__ float red[256 * 8];
+  const int U = C >> 3;
+  const int PL = 256 / U;                 // pixel lanes per block (host guarantees U <= 256)
+  const int tid = threadIdx.x;
+  const int u = tid % U, pl = tid / U;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+  float s[K][8];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[k][i] = 0.f;
+  if (pl < PL) {
+    for (int p = p0 + pl; p < p1; p += PL) {
+      const size_t off = ((size_t)n * HW + p) * C + u * 8;
+      float va[8];
+      U8<T>::load(a + off, va);
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s[0][i] += va[i]; s[1][i] += va[i] * va[i]; }
+      } else {
+        float vx[8];
+        if (relu) {
+          float vy[8];
+          U8<T>::load(b + off, vy);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) va[i] = vy[i] > 0.f ? va[i] : 0.f;
+        }
+        U8<T>::load(c + off, vx);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s[0][i] += va[i]; s[1][i] += va[i] * vx[i]; }
+        if (d) {
+          U8<T>::load(d + off, vx);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) s[2][i] += va[i] * vx[i];
+        }
+      }
+    }
+  }
+  // reduce over pixel lanes through LDS, one quantity at a time
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    __syncthreads();
+    if (pl < PL) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[(pl * U + u) * 8 + i] = s[k][i];
+    }
+    __syncthreads();
+    for (int ch = tid; ch < U * 8; ch += 256) {
+      float t = 0.f;
+      for (int q = 0; q < PL; ++q) t += red[q * U * 8 + ch];
+      unsafeAtomicAdd(sums + ((size_t)n * C + ch) * K + k, t);
+    }
+  }
+}
+
+__global__ void norm_finalize_kernel(const float* __restrict__ sums, int N, int HW, int C, int Creal, int instance,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     float* running_mean, float* running_var, int eval_mode, float eps,
+                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                     float* __restrict__ scale, float* __restrict__ shift) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = instance ? N * C : C;
+  if (idx >= total) return;
+  const int c = idx % C;
+  float m, var;
+  if (instance) {
+    const float cnt = (float)HW;
+    m = sums[(size_t)idx * 2] / cnt;
+    var = fmaxf(sums[(size_t)idx * 2 + 1] / cnt - m * m, 0.f);
+  } else if (eval_mode) {
+    m = c < Creal ? running_mean[c] : 0.f;
+    var = c < Creal ? running_var[c] : 1.f;
+  } else {
+    double s0 = 0.0, s1 = 0.0;
+    for (int n = 0; n < N; ++n) { s0 += sums[((size_t)n * C + c) * 2]; s1 += sums[((size_t)n * C + c) * 2 + 1]; }
+    const double cnt = (double)N * HW;
+    const double md = s0 / cnt;
+    const double vd = fmax(s1 / cnt - md * md, 0.0);
+    m = (float)md; var = (float)vd;
+    if (running_mean && c < Creal) {
+      running_mean[c] = 0.9f * running_mean[c] + 0.1f * m;
+      running_var[c] = 0.9f * running_var[c] + 0.1f * (float)(vd * cnt / fmax(cnt - 1.0, 1.0));
+    }
+  }
+  const float r = rsqrtf(var + eps);
+  mean[idx] = m; rstd[idx] = r;
+  const float gmm = c < Creal ? gamma[c] : 0.f, bt = c < Creal ? beta[c] : 0.f;
+  scale[idx] = gmm * r;
+  shift[idx] = bt - m * gmm * r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const T* __restrict__ r,
+                                                          const float* __restrict__ scale2, const float* __restrict__ shift2,
+                                                          T* __restrict__ y, int HW, int C, size_t units, int s1_per_n, int relu) {
+  const int U = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (size_t)gridDim.x * blockDim.x) {
+    const int u = (int)(i % U);
+    const size_t pix = i / U;
+    const int n = (int)(pix / HW);
+    float v[8], sc[8], sf[8];
+    U8<T>::load(x + i * 8, v);
+    const size_t cidx = (s1_per_n ? (size_t)n * C : 0) + u * 8;
+    U8<float>::load(scale + cidx, sc);
+    U8<float>::load(shift + cidx, sf);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = v[k] * sc[k] + sf[k];
+    if (r) {
+      float w[8];
+      U8<T>::load(r + i * 8, w);
+      U8<float>::load(scale2 + (size_t)n * C + u * 8, sc);
+      U8<float>::load(shift2 + (size_t)n * C + u * 8, sf);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += w[k] * sc[k] + sf[k];
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    U8<T>::store(y + i * 8, v);
+  }
+}
+
+// k1[c][3] for the batch branch, k2[n][c][3] for the instance branch
+__global__ void norm_bwd_finalize_kernel(const float* __restrict__ sums3, int N, int HW, int C, int Creal,
+                                         const float* gamma1, const float* mean1, const float* rstd1,
+                                         float* dgamma1, float* dbeta1, float* k1,
+                                         const float* gamma2, const float* mean2, const float* rstd2,
+                                         float* dgamma2, float* dbeta2, float* k2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const bool real = c < Creal;
+  double S0 = 0.0, S1 = 0.0;
+  for (int n = 0; n < N; ++n) { S0 += sums3[((size_t)n * C + c) * 3]; S1 += sums3[((size_t)n * C + c) * 3 + 1]; }
+  if (k1) {
+    if (real) {
+      const double P = (double)N * HW, g = gamma1[c], m = mean1[c], r = rstd1[c];
+      const double Q = r * (S1 - m * S0);
+      if (dgamma1) dgamma1[c] += (float)Q;
+      if (dbeta1) dbeta1[c] += (float)S0;
+      k1[c * 3 + 0] = (float)(g * r);
+      k1[c * 3 + 1] = (float)(-g * r * r * Q / P);
+      k1[c * 3 + 2] = (float)(-g * r * S0 / P + g * r * r * m * Q / P);
+    } else { k1[c * 3] = k1[c * 3 + 1] = k1[c * 3 + 2] = 0.f; }
+  }
+  if (k2) {
+    double dg = 0.0;
+    for (int n = 0; n < N; ++n) {
+      const size_t i = (size_t)n * C + c;
+      if (real) {
+        const double T0 = sums3[i * 3], T2 = sums3[i * 3 + 2];
+        const double P = (double)HW, g = gamma2[c], m = mean2[i], r = rstd2[i];
+        const double Q = r * (T2 - m * T0);
+        dg += Q;
+        k2[i * 3 + 0] = (float)(g * r);
+        k2[i * 3 + 1] = (float)(-g * r * r * Q / P);
+        k2[i * 3 + 2] = (float)(-g * r * T0 / P + g * r * r * m * Q / P);
+      } else { k2[i * 3] = k2[i * 3 + 1] = k2[i * 3 + 2] = 0.f; }
+    }
+    if (real) { if (dgamma2) dgamma2[c] += (float)dg; if (dbeta2) dbeta2[c] += (float)S0; }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                              const T* __restrict__ x, const T* __restrict__ r,
+                                                              const float* __restrict__ k1, const float* __restrict__ k2,
+                                                              T* __restrict__ dx, T* __restrict__ dr, int HW, int C,
+                                                              size_t units, int relu) {
+  const int U = C >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (size_t)gridDim.x * blockDim.x) {
+    const int u = (int)(i % U);
+    const size_t pix = i / U;
+    const int n = (int)(pix / HW);
+    float dz[8], v[8], o[8];
+    U8<T>::load(dy + i * 8, dz);
+    if (relu) {
+      U8<T>::load(y + i * 8, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dz[k] = v[k] > 0.f ? dz[k] : 0.f;
+    }
+    if (dx) {
+      if (k1) {
+        U8<T>::load(x + i * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float* kk = k1 + (u * 8 + k) * 3;
+          o[k] = kk[0] * dz[k] + kk[1] * v[k] + kk[2];
+        }
+        U8<T>::store(dx + i * 8, o);
+      } else {
+        U8<T>::store(dx + i * 8, dz);   // plain ReLU backward
+      }
+    }
+    if (dr) {
+      U8<T>::load(r + i * 8, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float* kk = k2 + ((size_t)n * C + u * 8 + k) * 3;
+        o[k] = kk[0] * dz[k] + kk[1] * v[k] + kk[2];
+      }
+      U8<T>::store(dr + i * 8, o);
+    }
+  }
+}
+
+// ---- LayerNorm over the last dim (rows x D), one wave per row, f32 --------------
+__global__ void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
+                                     float* __restrict__ rstd, int rows, int D, float eps) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += xr[i];
+  const float m = wave_sum(s) / D;
+  float q = 0.f;
+  for (int i = lane; i < D; i += 64) { const float d = xr[i] - m; q += d * d; }
+  const float r = rsqrtf(wave_sum(q) / D + eps);
+  for (int i = lane; i < D; i += 64) y[(size_t)row * D + i] = (xr[i] - m) * r * gamma[i] + beta[i];
+  if (lane == 0) { mean[row] = m; rstd[row] = r; }
+}
+
+__global__ void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, float* __restrict__ dx, float* dgamma, float* dbeta,
+                                     int rows, int D) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float m = mean[row], r = rstd[row];
+  const float* xr = x + (size_t)row * D;
+  const float* dr = dy + (size_t)row * D;
+  float a = 0.f, b = 0.f;
+  for (int i = lane; i < D; i += 64) {
+    const float xh = (xr[i] - m) * r, g = dr[i] * gamma[i];
+    a += g; b += g * xh;
+  }
+  a = wave_sum(a) / D; b = wave_sum(b) / D;
+  for (int i = lane; i < D; i += 64) {
+    const float xh = (xr[i] - m) * r, g = dr[i] * gamma[i];
+    dx[(size_t)row * D + i] = r * (g - a - xh * b);
+    if (dgamma) unsafeAtomicAdd(dgamma + i, dr[i] * xh);
+    if (dbeta) unsafeAtomicAdd(dbeta + i, dr[i]);
+  }
+}
+
+int grid_for(size_t n, int block = 256) { return (int)std::min<size_t>((n + block - 1) / block, 256 * 16); }
+
+}  // namespace
+
+extern "C" int ast_chan_stats(const void* x, float* sums, int N, int HW, int C, int dtype, void* stream) {
+  if (!x || !sums || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || C > 2048) AST_FAIL("ast_chan_stats: bad args N=%d HW=%d C=%d", N, HW, C);
+  hipStream_t s = (hipStream_t)stream;
+  AST_HIP(hipMemsetAsync(sums, 0, sizeof(float) * (size_t)N * C * 2, s));
+  const int PL = 256 / (C >> 3);
+  const int nblk = max(1, min((HW + PL - 1) / PL, max(1, 2048 / N)));
+  const int ppb = (HW + nblk - 1) / nblk;
+  dim3 grid((HW + ppb - 1) / ppb, N);
+  AST_DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 0>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr,
+                                            (const T*)nullptr, (const T*)nullptr, sums, HW, C, ppb, 0));
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_norm_finalize(const float* sums, int N, int HW, int C, int Creal, int instance, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, int eval_mode, float eps,
+                                 float* mean, float* rstd, float* scale, float* shift, void* stream) {
+  if (!gamma || !beta || !mean || !rstd || !scale || !shift) AST_FAIL("ast_norm_finalize: null pointer");
+  if (!eval_mode && !sums) AST_FAIL("ast_norm_finalize: sums required in training mode");
+  if (eval_mode && (instance || !running_mean || !running_var)) AST_FAIL("ast_norm_finalize: eval mode needs running stats");
+  const int total = instance ? N * C : C;
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, N, HW, C,
+                     Creal, instance, gamma, beta, running_mean, running_var, eval_mode, eps, mean, rstd, scale, shift);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_affine_act(const void* x, const float* scale, const float* shift, const void* r, const float* scale2,
+                              const float* shift2, void* y, int N, int HW, int C, int relu, int dtype, void* stream) {
+  if (!x || !scale || !shift || !y || (C & 7) || (r && (!scale2 || !shift2))) AST_FAIL("ast_affine_act: bad args");
+  const size_t units = (size_t)N * HW * (C >> 3);
+  // scale given per channel ([C]); the instance form ([N][C]) is requested with relu bit 2
+  const int s1_per_n = (relu >> 1) & 1;
+  AST_DISPATCH_T(dtype, hipLaunchKernelGGL((affine_act_kernel<T>), dim3(grid_for(units)), dim3(256), 0, (hipStream_t)stream,
+                                            (const T*)x, scale, shift, (const T*)r, scale2, shift2, (T*)y, HW, C, units,
+                                            s1_per_n, relu & 1));
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_norm_bwd_sums(const void* dy, const void* y, const void* x, const void* r, float* sums3, int N, int HW,
+                                 int C, int relu, int dtype, void* stream) {
+  if (!dy || !x || !sums3 || (relu && !y) || (C & 7) || C > 2048) AST_FAIL("ast_norm_bwd_sums: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  AST_HIP(hipMemsetAsync(sums3, 0, sizeof(float) * (size_t)N * C * 3, s));
+  const int PL = 256 / (C >> 3);
+  const int nblk = max(1, min((HW + PL - 1) / PL, max(1, 2048 / N)));
+  const int ppb = (HW + nblk - 1) / nblk;
+  dim3 grid((HW + ppb - 1) / ppb, N);
+  AST_DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)dy, (const T*)y,
+                                            (const T*)x, (const T*)r, sums3, HW, C, ppb, relu));
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_norm_bwd_finalize(const float* sums3, int N, int HW, int C, int Creal, const float* gamma1,
+                                     const float* mean1, const float* rstd1, float* dgamma1, float* dbeta1, float* k1,
+                                     const float* gamma2, const float* mean2, const float* rstd2, float* dgamma2,
+                                     float* dbeta2, float* k2, void* stream) {
+  if (!sums3 || (k1 && (!gamma1 || !mean1 || !rstd1)) || (k2 && (!gamma2 || !mean2 || !rstd2))) AST_FAIL("ast_norm_bwd_finalize: bad args");
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums3, N, HW, C, Creal,
+                     gamma1, mean1, rstd1, dgamma1, dbeta1, k1, gamma2, mean2, rstd2, dgamma2, dbeta2, k2);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_norm_bwd_apply(const void* dy, const void* y, const void* x, const void* r, const float* k1,
+                                  const float* k2, void* dx, void* dr, int N, int HW, int C, int relu, int dtype,
+                                  void* stream) {
+  if (!dy || (relu && !y) || (dx && k1 && !x) || (dr && (!r || !k2)) || (C & 7)) AST_FAIL("ast_norm_bwd_apply: bad args");
+  const size_t units = (size_t)N * HW * (C >> 3);
+  AST_DISPATCH_T(dtype, hipLaunchKernelGGL((norm_bwd_apply_kernel<T>), dim3(grid_for(units)), dim3(256), 0,
+                                            (hipStream_t)stream, (const T*)dy, (const T*)y, (const T*)x, (const T*)r, k1, k2,
+                                            (T*)dx, (T*)dr, HW, C, units, relu));
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                 int rows, int D, float eps, int dtype, void* stream) {
+  if (dtype != AST_F32) AST_FAIL("ast_layernorm_fwd: f32 only (token tensors are kept in f32)");
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || D <= 0) AST_FAIL("ast_layernorm_fwd: bad args");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma,
+                     beta, (float*)y, mean, rstd, rows, D, eps);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                 void* dx, float* dgamma, float* dbeta, int rows, int D, int dtype, void* stream) {
+  if (dtype != AST_F32) AST_FAIL("ast_layernorm_bwd: f32 only");
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || D <= 0) AST_FAIL("ast_layernorm_bwd: bad args");
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
+                     (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, rows, D);
+  AST_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,64 @@
+// Optimiser step over flat f32 parameter/gradient buffers (HBM-bound streaming):
+// global gradient-norm clipping + Adam in two launches for the whole model.
+#include "ast_common.h"
+#include "../../include/ast_hip.h"
+
+namespace {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+  __shared__ float red[17];
+  float q = 0.f;
+  const size_t n4 = n / 4;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = x4[i];
+    q += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[n4 * 4 + threadIdx.x]; q += v * v; }
+  q = block_sum(q, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, q);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                                                    const int64_t* __restrict__ d_step, const float* __restrict__ gnorm_sq, float max_norm) {
+  const float step = (float)(*d_step);
+  const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+  float clip = 1.f;
+  if (gnorm_sq) clip = fminf(1.f, max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f));
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * clip;
+    if (wd != 0.f) gi += wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+  }
+}
+__global__ void counter_incr_kernel(int64_t* c) { if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += 1; }
+}  // namespace
+
+extern "C" int ast_sumsq(const float* x, int64_t n, float* out, void* stream) {
+  if (!x || !out || n < 0) AST_FAIL("ast_sumsq: bad args");
+  if (n == 0) return 0;
+  if (((uintptr_t)x) & 15) AST_FAIL("ast_sumsq: x must be 16-byte aligned");
+  const int grid = (int)std::min<size_t>(((size_t)n / 4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, out);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int ast_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                        const int64_t* d_step, const float* gnorm_sq, float max_norm, void* stream) {
+  if (!p || !g || !m || !v || !d_step || n < 0) AST_FAIL("ast_adam: bad args");
+  if (n == 0) return 0;
+  const int grid = (int)std::min<size_t>(((size_t)n + 255) / 256, 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, lr, b1, b2, eps, wd, d_step,
+                     gnorm_sq, max_norm);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int ast_counter_incr(int64_t* c, void* stream) {
+  if (!c) AST_FAIL("ast_counter_incr: null");
+  hipLaunchKernelGGL(counter_incr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c);
+  AST_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,200 @@
+/* libast_hip.so -- C ABI of the MI355X (gfx950) hot path.
+ *
+ * The reference (francescobrigante/Audio-Style-Transfer) is pure Python: it has
+ * no FFI of its own.  The boundary this library replaces is the set of
+ * torch/ATen operator calls made by the reference's nn.Module.forward / loss
+ * functions; each entry point cites the reference call site it stands in for.
+ * The host side (audio-style-transfer_amd/ast_amd) binds these with ctypes and
+ * keeps the reference's Python call surface.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named h_*; the library borrows it
+ *     for the duration of the enqueue, allocates nothing, never synchronises and
+ *     enqueues on `stream` (a hipStream_t passed as void*), so calls are
+ *     hipGraph-capturable;
+ *   - return 0 on success, negative on error; ast_last_error() returns the
+ *     message (thread-local);
+ *   - activations are NHWC with the channel count padded to a multiple of 8;
+ *     `dtype` selects their storage / MFMA operand type: AST_F32 (exact f32
+ *     MFMA) or AST_BF16 (bf16 MFMA, f32 accumulate); parameters, statistics and
+ *     losses are always f32.
+ */
+#ifndef AST_HIP_H
+#define AST_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AST_DTYPE_F32 0
+#define AST_DTYPE_BF16 1
+#define AST_MAX_TAPS 9
+
+int ast_version(void);
+const char* ast_last_error(void);
+
+/* Geometry of one gathered (implicit im2col) GEMM.  Rows of the GEMM are the
+ * pixels (n, hm, wm) of a logical Hm x Wm grid; tap t reads source pixel
+ * (hm*sh + oh + dh[t], wm*sw + ow + dw[t]) (zero outside the tensor) and weight
+ * slice wtap[t]; the result goes to destination pixel (hm*dsh + doh, wm*dsw + dow).
+ * This one description covers Conv2d forward, its data gradient (one launch per
+ * output-parity class for stride 2), ConvTranspose2d forward/backward and
+ * nn.Linear (H = W = 1, one tap). */
+typedef struct ast_gather_t {
+  int32_t N, Hs, Ws, Cs;          /* source NHWC, Cs multiple of 8 */
+  int32_t Hm, Wm;                 /* logical pixel grid */
+  int32_t sh, sw, oh, ow;         /* source base coordinate */
+  int32_t Hd, Wd, Cd;             /* destination NHWC, Cd multiple of 8 */
+  int32_t dsh, dsw, doh, dow;     /* destination coordinate */
+  int32_t ntaps, wtaps;           /* taps used / taps per weight row */
+  int32_t tap[AST_MAX_TAPS];      /* (dh+64) | (dw+64)<<8 | wtap<<16 */
+} ast_gather_t;
+
+/* dst[pix][co] (+)= sum_{t,c} src[gather(pix,t)][c] * wgt[co][wtap[t]][c] + bias[co]
+ * Replaces: nn.Conv2d fwd/bwd-data (style_encoder.py:50-67, new_decoder.py:29-61),
+ * nn.ConvTranspose2d fwd/bwd-data (new_decoder.py:72-96), nn.Linear fwd/bwd-data.
+ * flags: bit0 accumulate into dst, bit1 ReLU. */
+int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst,
+              const ast_gather_t* g, int dtype, int flags, void* stream);
+
+/* dw[cd][wtap[t]][c] += sum_pix dy[pix][cd] * src[gather(pix,t)][c]   (f32 atomics)
+ * dy is the plain operand over the logical grid (N,Hm,Wm,Cd).
+ * Replaces: weight gradients of Conv2d / ConvTranspose2d / Linear. */
+int ast_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t* g,
+              int dtype, void* stream);
+
+/* ---- layout conversion at the module boundary ------------------------------ */
+/* x (N,C,H,W) f32, element (n,c,h,w) at n*sn + c*sc + h*sh + w  ->  NHWC dtype, Cp>=C zero padded.
+ * Replaces the implicit NCHW contract of x.view(B*S,C,T,F) (style_encoder.py:213). */
+int ast_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int64_t sn, int64_t sc,
+                     int64_t sh, int Cp, int dtype, void* stream);
+int ast_nhwc_to_nchw(const void* x, float* y, int N, int C, int H, int W, int Cp, int dtype, void* stream);
+/* dtype casts of flat buffers */
+int ast_cast(const void* x, int dtype_in, void* y, int dtype_out, int64_t n, void* stream);
+
+/* ---- spectral norm + weight packing (torch spectral_norm.py:92-114) --------- */
+typedef struct ast_weight_desc_t {
+  const float* w;       /* weight_orig; element (co,ci,tap) at co*s_co + ci*s_ci + tap */
+  float* u;             /* weight_u [Co] or NULL (no spectral norm) */
+  float* v;             /* weight_v [Ci*KK] */
+  float* sigma;         /* [1] out */
+  float* scratch;       /* [Co + Ci*KK] */
+  void* wf;             /* packed [Cop][KK][Cip]  (rows = out channel) or NULL */
+  void* wb;             /* packed [Cip][KK][Cop]  (rows = in channel) or NULL */
+  int32_t Co, Ci, KK, s_co, s_ci, Cop, Cip;
+  int32_t power_iter;   /* 1 in training, 0 in eval */
+} ast_weight_desc_t;
+/* descs: DEVICE array of n descriptors, dtypes: DEVICE int[n] (packed dtype per weight).
+ * Runs the power iteration (if requested), sigma = u^T W v, and writes W/sigma in both
+ * packed layouts -- three launches for all n weights.  max_co / max_cols / max_packed are
+ * the maxima over the descriptors of Co, Ci*KK and Cop*KK*Cip (grid sizing). */
+int ast_weights_prepare_v(const ast_weight_desc_t* descs, const int* dtypes, int n, int max_co, int max_cols,
+                          long max_packed, void* stream);
+/* g_orig += (dWp - <dWp,W/sigma> u v^T)/sigma, dWp packed [Cop][KK][Cip] (from_wb=0)
+ * or [Cip][KK][Cop] (from_wb=1).  u NULL => plain unpack-accumulate. */
+int ast_weight_grad_unpack(const float* dwp, int from_wb, const float* w, const float* u, const float* v,
+                           const float* sigma, float* g_orig, int Co, int Ci, int KK, int s_co, int s_ci,
+                           int Cop, int Cip, float* scratch, void* stream);
+
+/* ---- normalisation (nn.BatchNorm2d / nn.InstanceNorm2d / nn.LayerNorm) ------ */
+/* sums[n][c][k]: k=0 sum x, k=1 sum x^2 over the H*W pixels of image n (buffer zeroed inside). */
+int ast_chan_stats(const void* x, float* sums, int N, int HW, int C, int dtype, void* stream);
+/* From sums -> per-channel (batch) or per-(n,c) (instance) scale/shift; updates
+ * running stats when running_mean != NULL (momentum 0.1, unbiased var). eval_mode uses running stats. */
+int ast_norm_finalize(const float* sums, int N, int HW, int C, int Creal, int instance,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      int eval_mode, float eps, float* mean, float* rstd, float* scale, float* shift,
+                      void* stream);
+/* y = act(x*scale[c] + shift[c] + r*scale2[n,c] + shift2[n,c]) ; r may be NULL.
+ * flags: bit0 ReLU, bit1 scale/shift are per (n,c) instead of per c. */
+int ast_affine_act(const void* x, const float* scale, const float* shift, const void* r,
+                   const float* scale2, const float* shift2, void* y, int N, int HW, int C,
+                   int flags, int dtype, void* stream);
+/* backward of the above followed by the norm backward:
+ * dz = dy * (y>0 if relu); sums3[n][c] = {sum dz, sum dz*x, sum dz*r} */
+int ast_norm_bwd_sums(const void* dy, const void* y, const void* x, const void* r, float* sums3,
+                      int N, int HW, int C, int relu, int dtype, void* stream);
+/* coefficients k[c][3] (batch branch) and j[n][c][3] (instance branch) and dgamma/dbeta accumulation */
+int ast_norm_bwd_finalize(const float* sums3, int N, int HW, int C, int Creal,
+                          const float* gamma1, const float* mean1, const float* rstd1,
+                          float* dgamma1, float* dbeta1, float* k1,
+                          const float* gamma2, const float* mean2, const float* rstd2,
+                          float* dgamma2, float* dbeta2, float* k2, void* stream);
+/* dx = k1[c][0]*dz + k1[c][1]*x + k1[c][2];  dr = k2[n][c][0]*dz + k2[n][c][1]*r + k2[n][c][2] */
+int ast_norm_bwd_apply(const void* dy, const void* y, const void* x, const void* r,
+                       const float* k1, const float* k2, void* dx, void* dr,
+                       int N, int HW, int C, int relu, int dtype, void* stream);
+
+int ast_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                      float* rstd, int rows, int D, float eps, int dtype, void* stream);
+int ast_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                      const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int D,
+                      int dtype, void* stream);
+
+/* ---- pooling / resampling ---------------------------------------------------- */
+/* nn.AdaptiveAvgPool2d with bins [floor(i*In/Out), ceil((i+1)*In/Out)) (style_encoder.py:113-114, new_decoder.py:51) */
+int ast_adaptive_pool_fwd(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int dtype, void* stream);
+int ast_adaptive_pool_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int dtype, void* stream);
+/* nn.Upsample(bilinear, align_corners=False) NHWC(Cp) -> NCHW f32 (new_decoder.py:99) */
+int ast_bilinear_fwd(const void* x, float* y, int N, int C, int Cp, int H, int W, int Ho, int Wo, int dtype, void* stream);
+int ast_bilinear_bwd(const float* dy, void* dx, int N, int C, int Cp, int H, int W, int Ho, int Wo, int dtype, void* stream);
+
+/* ---- small-sequence attention core (nn.MultiheadAttention inner product part) - */
+/* q:(B,Lq,ldq) k,v:(B,Lk,ldk) rows of f32 (already projected); heads of width dh; causal optional;
+ * p_out (B,H,Lq,Lk) saved probabilities (after dropout mask scaling); drop_mask optional (B,H,Lq,Lk) of 0/1/(1-p) */
+int ast_attn_fwd(const float* q, const float* k, const float* v, float* o, float* probs,
+                 int B, int H, int Lq, int Lk, int dh, int ldq, int ldk, int ldo, int causal,
+                 const float* drop_mask, void* stream);
+int ast_attn_bwd(const float* dout, const float* q, const float* k, const float* v, const float* probs,
+                 float* dq, float* dk, float* dv, int B, int H, int Lq, int Lk, int dh, int ldq,
+                 int ldk, int ldo, const float* drop_mask, void* stream);
+
+/* ---- elementwise ------------------------------------------------------------- */
+/* out[c] += sum_r x[r][c], c < Creal  (bias gradients of Conv2d / Linear) */
+int ast_colsum_acc(const void* x, int64_t rows, int C, int Creal, float* out, int dtype, void* stream);
+int ast_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
+int ast_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
+/* counter-based dropout: mask[i] in {0, 1/(1-p)} (f32), y = x*mask */
+int ast_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, const int64_t* d_offset, void* stream);
+int ast_mul(const void* a, const float* mask, void* y, int64_t n, int dtype, void* stream);
+
+/* ---- losses -------------------------------------------------------------------- */
+/* compute_comprehensive_loss (new_decoder.py:348-420), one pass: out (B,S,2,T,F) f32 contiguous,
+ * tgt same logical shape with row stride tgt_ld (a [..., :513] view of x).  sums[5] raw sums
+ * (mse, mag, phase, temporal, spectral); grad = d total / d out (may be NULL). */
+int ast_recon_loss(const float* out, const float* tgt, int64_t tgt_ld, int B, int S, int T, int Fq,
+                   float w_mse, float w_mag, float w_phase, float w_temporal, float w_spectral,
+                   float* sums, float* grad, void* stream);
+/* losses.py on (B,256) embeddings; each writes loss[0] and optional gradients */
+int ast_infonce(const float* emb, const int32_t* labels, int B, int D, float temperature,
+                float* loss, float* demb, float* ws /* 2*B*B + B floats */, void* stream);
+int ast_margin(const float* cls, int C, int D, float margin, float* loss, float* dcls, void* stream);
+int ast_hsic(const float* s, const float* c, int B, int D, float* loss, float* ds, float* dc,
+             float* ws /* 6*B*B + 2*B + 8 floats */, void* stream);
+/* mean cross entropy over rows of logits (R,C); dlogits optional */
+int ast_cross_entropy(const float* logits, const int32_t* target, int R, int C, float* loss, float* dlogits, void* stream);
+/* mean entropy with log(p+1e-8) (losses.py:118-120) */
+int ast_softmax_entropy(const float* logits, int R, int C, float* loss, float* dlogits, void* stream);
+
+/* y = (accumulate ? y : 0) + hscale * (dscale ? *dscale : 1) * x   (chain rule for scalar losses) */
+int ast_scale(const float* x, const float* dscale, float hscale, float* y, int64_t n, int accumulate, void* stream);
+
+/* ---- optimiser ------------------------------------------------------------------ */
+int ast_counter_incr(int64_t* c, void* stream);
+int ast_sumsq(const float* x, int64_t n, float* out /* accumulates */, void* stream);
+/* Adam with bias correction; grad scaled by min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) when gnorm_sq != NULL */
+int ast_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+             float eps, float wd, const int64_t* d_step, const float* gnorm_sq, float max_norm, void* stream);
+
+/* ---- STFT front-end (utilityFunctions.py:12-37 + dataloader.py:9-13 + utilityFunctions.py:240-263) */
+/* wave (Bc, nsamp) f32 -> x (Bc, S, 2, 287, F_total) f32: frames of a 1024-point Hann STFT (hop 256,
+ * reflect padded), z-scored with mean/std (2,513), cut into S sections of 287 frames (step 191), written
+ * to bins [0,513) of the F_total-wide rows. */
+int ast_stft_sections(const float* wave, int Bc, int nsamp, const float* mean, const float* std_,
+                      float* x, int S, int win, int step, int F_total, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,449 @@
+"""Op-level parity of the HIP kernels (through the C-ABI) against fp32 CPU
+references: torch.nn.functional for dense ops, oracle/ for the restated ones.
+Tolerances: f32 path 1e-4 relative to the tensor scale (f32 MFMA is an exact fmaf
+chain; only summation order differs); bf16 path 2e-2 (8-bit mantissa operands,
+f32 accumulation)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils import spectral_norm
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import ast_amd
+    from ast_amd import config, layers as AL, ops
+from oracle import ast_oracle as O
+from oracle import frontend_oracle as FO
+from oracle import seeded_params as sp
+
+DEV = "cuda"
+TOL = {torch.float32: 2e-4, torch.bfloat16: 3e-2}
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(b.abs().max().item(), 1e-12))
+
+
+def to_nhwc(x, dtype):
+    return ops.nchw_to_nhwc(x.to(DEV).contiguous(), dtype)
+
+
+def from_nhwc(y, C):
+    return y[..., :C].permute(0, 3, 1, 2).float().cpu()
+
+
+def make_bank(mods, kinds, dtype):
+    config.set_compute_dtype(dtype)
+    bank = AL.WeightBank()
+    pws = []
+    for m, kind in zip(mods, kinds):
+        if kind == "linear":
+            pws.append(bank.add(m.weight, "linear", AL.tok_dtype, bias=m.bias))
+        else:
+            pws.append(bank.add(m.weight_orig, kind, AL.img_dtype, u=m.weight_u, v=m.weight_v, bias=m.bias))
+    return bank, pws
+
+
+def sn_reference_weight(m, dim):
+    """one power iteration + sigma, on a CPU copy of the buffers (oracle.spectral_weight)."""
+    sd = {"weight_orig": m.weight_orig.detach().cpu().clone().requires_grad_(True),
+          "weight_u": m.weight_u.detach().cpu().clone(), "weight_v": m.weight_v.detach().cpu().clone()}
+    w = O.spectral_weight(sd, "", O.Cfg(training=True), dim=dim)
+    return w, sd
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,N", [
+    (2, 32, 3, 2, 37, 53, 2),      # padded-input first layer, odd sizes
+    (32, 32, 3, 1, 19, 23, 3),
+    (32, 64, 3, 2, 18, 38, 2),
+    (64, 128, 3, 2, 9, 19, 2),
+    (128, 256, 3, 1, 5, 10, 2),
+    (16, 64, 1, 2, 11, 14, 2),     # shortcut conv
+    (64, 1, 1, 1, 32, 16, 2),      # spatial_projection.3
+    (2, 16, 3, 1, 30, 41, 1),
+])
+def test_conv2d_fwd_bwd(dtype, cin, cout, k, stride, H, W, N):
+    torch.manual_seed(0)
+    pad = 1 if k == 3 else 0
+    m = spectral_norm(nn.Conv2d(cin, cout, k, stride=stride, padding=pad)).to(DEV)
+    with torch.no_grad():
+        m.bias.normal_(0, 0.1)
+    wref, sd = sn_reference_weight(m, 0)
+    x = torch.randn(N, cin, H, W)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wref, m.bias.detach().cpu(), stride=stride, padding=pad)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+
+    bank, (pw,) = make_bank([m], ["conv"], dtype)
+    bank.prepare(True)
+    xh = to_nhwc(x, dtype).requires_grad_(True)
+    y = AL.conv(xh, pw, k, stride, pad, True)
+    assert y.shape == (N, yr.shape[2], yr.shape[3], ops.pad8(cout))
+    tol = TOL[dtype]
+    assert rel_err(from_nhwc(y, cout), yr) < tol
+    if ops.pad8(cout) != cout:
+        assert float(y[..., cout:].abs().max()) == 0.0
+    y.backward(to_nhwc(gy, dtype))
+    assert rel_err(from_nhwc(xh.grad, cin), xr.grad) < tol
+    assert rel_err(m.weight_orig.grad, sd["weight_orig"].grad) < tol
+    assert rel_err(m.bias.grad, gy.sum(dim=(0, 2, 3))) < tol
+    # power iteration side effects (torch spectral_norm.py:97-113)
+    assert rel_err(m.weight_u, sd["weight_u"]) < 1e-4 and rel_err(m.weight_v, sd["weight_v"]) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,stride,H,W", [(1, 64, 2, 8, 6), (64, 32, 2, 9, 7), (16, 8, 2, 12, 10), (8, 2, 1, 14, 9)])
+def test_conv_transpose_fwd_bwd(dtype, cin, cout, stride, H, W):
+    torch.manual_seed(1)
+    op = 1 if stride == 2 else 0
+    m = spectral_norm(nn.ConvTranspose2d(cin, cout, 3, stride=stride, padding=1, output_padding=op)).to(DEV)
+    with torch.no_grad():
+        m.bias.normal_(0, 0.1)
+    wref, sd = sn_reference_weight(m, 1)
+    N = 2
+    x = torch.randn(N, cin, H, W)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wref, m.bias.detach().cpu(), stride=stride, padding=1, output_padding=op)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    bank, (pw,) = make_bank([m], ["convT"], dtype)
+    bank.prepare(True)
+    xh = to_nhwc(x, dtype).requires_grad_(True)
+    y = AL.convT(xh, pw, 3, stride, 1, op, True)
+    tol = TOL[dtype]
+    assert rel_err(from_nhwc(y, cout), yr) < tol
+    y.backward(to_nhwc(gy, dtype))
+    assert rel_err(from_nhwc(xh.grad, cin), xr.grad) < tol
+    assert rel_err(m.weight_orig.grad, sd["weight_orig"].grad) < tol
+    assert rel_err(m.bias.grad, gy.sum(dim=(0, 2, 3))) < tol
+
+
+@pytest.mark.parametrize("rows,fin,fout,relu", [(6, 256, 768, False), (24, 1024, 256, False), (10, 256, 1024, True), (5, 128, 2, False), (3, 512, 256, False)])
+def test_linear_fwd_bwd(rows, fin, fout, relu):
+    torch.manual_seed(2)
+    m = nn.Linear(fin, fout).to(DEV)
+    x = torch.randn(rows, fin)
+    xr = x.clone().requires_grad_(True)
+    wr, br = m.weight.detach().cpu().clone().requires_grad_(True), m.bias.detach().cpu().clone().requires_grad_(True)
+    yr = F.linear(xr, wr, br)
+    if relu:
+        yr = torch.relu(yr)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    bank, (pw,) = make_bank([m], ["linear"], torch.float32)
+    bank.prepare(True)
+    xh = x.to(DEV).requires_grad_(True)
+    y = AL.linear(xh, pw, relu=relu)
+    assert rel_err(y, yr) < 2e-4
+    y.backward(gy.to(DEV))
+    assert rel_err(xh.grad, xr.grad) < 2e-4
+    assert rel_err(m.weight.grad, wr.grad) < 2e-4
+    assert rel_err(m.bias.grad, br.grad) < 2e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,N,H,W", [(32, 3, 17, 21), (512, 4, 5, 10), (8, 2, 40, 33)])
+def test_batchnorm_relu(dtype, C, N, H, W):
+    torch.manual_seed(3)
+    Cr = C if C != 8 else 2
+    bn = nn.BatchNorm2d(Cr).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5)
+    ref = nn.BatchNorm2d(Cr)
+    ref.load_state_dict({k: v.cpu() for k, v in bn.state_dict().items()})
+    x = torch.randn(N, Cr, H, W) * 2 + 0.5
+    xq = from_nhwc(to_nhwc(x, dtype), Cr)          # the values the kernel actually sees
+    xr = xq.clone().requires_grad_(True)
+    yr = torch.relu(ref(xr))
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    xh = to_nhwc(x, dtype).requires_grad_(True)
+    y = AL.bn_act(xh, bn, True, relu=True)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    assert rel_err(from_nhwc(y, Cr), yr) < tol
+    y.backward(to_nhwc(gy, dtype))
+    assert rel_err(from_nhwc(xh.grad, Cr), xr.grad) < tol * 3
+    assert rel_err(bn.weight.grad, ref.weight.grad) < tol * 3 and rel_err(bn.bias.grad, ref.bias.grad) < tol * 3
+    assert rel_err(bn.running_mean, ref.running_mean) < 1e-4 and rel_err(bn.running_var, ref.running_var) < 1e-4
+    assert int(bn.num_batches_tracked) == 1
+    bn.eval(); ref.eval()
+    ye = AL.bn_act(to_nhwc(x, dtype), bn, False, relu=False)
+    assert rel_err(from_nhwc(ye, Cr), ref(xq)) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_resblock_tail(dtype):
+    torch.manual_seed(4)
+    N, C, H, W = 3, 64, 9, 13
+    bn, inn = nn.BatchNorm2d(C).to(DEV), nn.InstanceNorm2d(C, affine=True).to(DEV)
+    with torch.no_grad():
+        for m in (bn, inn):
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    rb, ri = nn.BatchNorm2d(C), nn.InstanceNorm2d(C, affine=True)
+    rb.load_state_dict({k: v.cpu() for k, v in bn.state_dict().items()})
+    ri.load_state_dict({k: v.cpu() for k, v in inn.state_dict().items()})
+    a, b = torch.randn(N, C, H, W), torch.randn(N, C, H, W) * 3 + 1
+    aq, bq = from_nhwc(to_nhwc(a, dtype), C), from_nhwc(to_nhwc(b, dtype), C)
+    ar, br = aq.clone().requires_grad_(True), bq.clone().requires_grad_(True)
+    yr = torch.relu(rb(ar) + ri(br))
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    ah, bh = to_nhwc(a, dtype).requires_grad_(True), to_nhwc(b, dtype).requires_grad_(True)
+    y = ops.ResTailFn.apply(ah, bh, bn.weight, bn.bias, inn.weight, inn.bias, bn, inn, True)
+    tol = 1e-4 if dtype == torch.float32 else 1e-2
+    assert rel_err(from_nhwc(y, C), yr) < tol
+    y.backward(to_nhwc(gy, dtype))
+    assert rel_err(from_nhwc(ah.grad, C), ar.grad) < 3 * tol and rel_err(from_nhwc(bh.grad, C), br.grad) < 3 * tol
+    for m, r in ((bn, rb), (inn, ri)):
+        assert rel_err(m.weight.grad, r.weight.grad) < 3 * tol and rel_err(m.bias.grad, r.bias.grad) < 3 * tol
+
+
+@pytest.mark.parametrize("H,W,Ho,Wo,C", [(5, 10, 2, 5, 512), (2, 5, 1, 1, 512), (36, 65, 32, 16, 64)])
+def test_adaptive_pool(H, W, Ho, Wo, C):
+    torch.manual_seed(5)
+    x = torch.randn(2, C, H, W)
+    xr = x.clone().requires_grad_(True)
+    yr = F.adaptive_avg_pool2d(xr, (Ho, Wo))
+    assert rel_err(O.adaptive_avg_pool2d(x, (Ho, Wo)), yr) < 1e-5
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    xh = to_nhwc(x, torch.float32).requires_grad_(True)
+    y = ops.AdaptivePoolFn.apply(xh, Ho, Wo)
+    assert rel_err(from_nhwc(y, C), yr) < 1e-5
+    y.backward(to_nhwc(gy, torch.float32))
+    assert rel_err(from_nhwc(xh.grad, C), xr.grad) < 1e-5
+
+
+def test_bilinear():
+    torch.manual_seed(6)
+    x = torch.randn(2, 2, 64, 32)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=(37, 65), mode="bilinear", align_corners=False)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    xh = to_nhwc(x, torch.float32).requires_grad_(True)
+    y = ops.BilinearToNCHWFn.apply(xh, 2, 37, 65)
+    assert rel_err(y, yr) < 1e-5
+    y.backward(gy.to(DEV))
+    assert rel_err(from_nhwc(xh.grad, 2), xr.grad) < 1e-5
+    # the decoder's real geometry (512,256)->(287,513), forward only against the oracle matrix form
+    x2 = torch.randn(1, 2, 512, 256)
+    y2 = ops.BilinearToNCHWFn.apply(to_nhwc(x2, torch.float32), 2, 287, 513)
+    assert rel_err(y2, F.interpolate(x2, size=(287, 513), mode="bilinear", align_corners=False)) < 1e-5
+    assert rel_err(y2, O.bilinear_resize(x2, (287, 513))) < 1e-4   # oracle indexes in float64, torch and the kernel in float32
+
+
+def test_layernorm():
+    torch.manual_seed(7)
+    ln = nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_(0, 0.2)
+    x = torch.randn(3, 5, 256) * 2 + 0.3
+    xr = x.clone().requires_grad_(True)
+    wr, br = ln.weight.detach().cpu().clone().requires_grad_(True), ln.bias.detach().cpu().clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (256,), wr, br)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    xh = x.to(DEV).requires_grad_(True)
+    y = AL.layer_norm(xh, ln)
+    assert rel_err(y, yr) < 1e-5
+    y.backward(gy.to(DEV))
+    assert rel_err(xh.grad, xr.grad) < 1e-4 and rel_err(ln.weight.grad, wr.grad) < 1e-4 and rel_err(ln.bias.grad, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("cross,causal,Lq,Lk", [(False, False, 3, 3), (False, True, 4, 4), (True, False, 2, 4), (False, False, 5, 5)])
+def test_mha(cross, causal, Lq, Lk):
+    torch.manual_seed(8)
+    d, h, B = 256, 4, 3
+    m = nn.MultiheadAttention(d, h, dropout=0.0, batch_first=True).to(DEV)
+    with torch.no_grad():
+        m.in_proj_bias.normal_(0, 0.1); m.out_proj.bias.normal_(0, 0.1)
+    ref = nn.MultiheadAttention(d, h, dropout=0.0, batch_first=True)
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    x, mem = torch.randn(B, Lq, d), torch.randn(B, Lk, d)
+    xr, memr = x.clone().requires_grad_(True), mem.clone().requires_grad_(True)
+    mask = torch.triu(torch.ones(Lq, Lq), diagonal=1).bool() if causal else None
+    yr, _ = ref(xr, memr if cross else xr, memr if cross else xr, attn_mask=mask, need_weights=False)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    config.set_compute_dtype(torch.float32)
+    bank = AL.WeightBank()
+    att = AL.MHA(bank, m, cross=cross)
+    bank.prepare(True)
+    xh, memh = x.to(DEV).requires_grad_(True), mem.to(DEV).requires_grad_(True)
+    y = att(xh, memh if cross else None, True, 0.0, causal=causal)
+    assert rel_err(y, yr) < 2e-4
+    y.backward(gy.to(DEV))
+    assert rel_err(xh.grad, xr.grad) < 2e-4
+    if cross:
+        assert rel_err(memh.grad, memr.grad) < 2e-4
+    assert rel_err(m.in_proj_weight.grad, ref.in_proj_weight.grad) < 2e-4
+    assert rel_err(m.in_proj_bias.grad, ref.in_proj_bias.grad) < 2e-4
+    assert rel_err(m.out_proj.weight.grad, ref.out_proj.weight.grad) < 2e-4
+
+
+def test_dropout_statistics():
+    x = torch.ones(200000, device=DEV, requires_grad=True)
+    y = ops.dropout(x, 0.1, True)
+    kept = float((y > 0).float().mean())
+    assert abs(kept - 0.9) < 5e-3 and abs(float(y.mean()) - 1.0) < 1e-2
+    y.sum().backward()
+    assert torch.equal(x.grad > 0, y > 0)
+    assert ops.dropout(x, 0.1, False) is x
+
+
+@pytest.mark.parametrize("B,S", [(2, 2), (3, 1)])
+def test_recon_loss(B, S):
+    torch.manual_seed(9)
+    T, Fq = 31, 45
+    full = torch.randn(B, S, 2, T, Fq + 7)
+    tgt = full[..., :Fq]
+    out = torch.randn(B, S, 2, T, Fq)
+    outr = out.clone().requires_grad_(True)
+    ref = O.comprehensive_loss(outr, tgt)
+    ref["total_loss"].backward()
+    oh = out.to(DEV).requires_grad_(True)
+    got = ast_amd.compute_comprehensive_loss(oh, full.to(DEV)[..., :Fq])
+    for k, v in ref.items():
+        assert math.isclose(float(got[k]), float(v), rel_tol=2e-4, abs_tol=1e-6), k
+    (got["total_loss"] * 1.7).backward()
+    assert rel_err(oh.grad, outr.grad * 1.7) < 1e-3
+
+
+@pytest.mark.parametrize("B", [2, 8, 16, 64])
+def test_embedding_losses(B):
+    rng = np.random.default_rng([77, B])
+    style = torch.tensor(rng.standard_normal((B, 256)).astype(np.float32))
+    content = torch.tensor(rng.standard_normal((B, 256)).astype(np.float32))
+    labels = sp.balanced_labels(B)
+    sr, cr = style.clone().requires_grad_(True), content.clone().requires_grad_(True)
+    sh, ch = style.to(DEV).requires_grad_(True), content.to(DEV).requires_grad_(True)
+    for name, ref, got in (
+            ("infonce", lambda: O.infonce_loss(sr, labels), lambda: ast_amd.infoNCE_loss(sh, labels)),
+            ("hsic", lambda: O.disentanglement_loss(sr, cr), lambda: ast_amd.disentanglement_loss(sh, ch))):
+        for t in (sr, cr, sh, ch):
+            t.grad = None
+        lr, lg = ref(), got()
+        assert math.isclose(float(lg), float(lr), rel_tol=5e-4, abs_tol=1e-7), (name, float(lg), float(lr))
+        if lr.requires_grad:
+            lr.backward(); lg.backward()
+            assert rel_err(sh.grad, sr.grad) < 2e-3, name
+            if cr.grad is not None:
+                assert rel_err(ch.grad, cr.grad) < 2e-3, name
+    cls = torch.stack([style[labels == 0].mean(0), style[labels == 1].mean(0)])
+    clr, clh = cls.clone().requires_grad_(True), cls.to(DEV).requires_grad_(True)
+    lr, lg = O.margin_loss(clr), ast_amd.margin_loss(clh)
+    assert math.isclose(float(lg), float(lr), rel_tol=1e-4, abs_tol=1e-7)
+    lr.backward(); lg.backward()
+    assert rel_err(clh.grad, clr.grad) < 1e-3 or float(clr.grad.abs().max()) == 0.0
+
+
+def test_loss_golden_and_known_answers(golden_dir):
+    g = np.load(os.path.join(golden_dir, "losses.npz"))
+    for B in (8, 16):
+        rng = np.random.default_rng([77, B])
+        style = torch.tensor(rng.standard_normal((B, 256)).astype(np.float32), device=DEV, requires_grad=True)
+        content = torch.tensor(rng.standard_normal((B, 3, 256)).astype(np.float32), device=DEV, requires_grad=True)
+        labels = sp.balanced_labels(B)
+        v = ast_amd.infoNCE_loss(style, labels)
+        assert math.isclose(float(v), float(g[f"B{B}_infonce"]), rel_tol=5e-4)
+        v.backward()
+        assert rel_err(style.grad, torch.tensor(g[f"B{B}_infonce_dstyle"])) < 2e-3
+        style.grad = None
+        v = ast_amd.disentanglement_loss(style, content.mean(1))
+        assert math.isclose(float(v), float(g[f"B{B}_hsic"]), rel_tol=5e-4)
+        v.backward()
+        assert rel_err(style.grad, torch.tensor(g[f"B{B}_hsic_dstyle"])) < 2e-3
+        assert rel_err(content.grad, torch.tensor(g[f"B{B}_hsic_dcontent"])) < 2e-3
+    # test_correctness.ipynb cell 9: identical embeddings B=16 -> ln 15
+    v = ast_amd.infoNCE_loss(torch.ones(16, 256, device=DEV), sp.balanced_labels(16))
+    assert math.isclose(float(v), math.log(15), rel_tol=1e-5)
+
+
+def test_adversarial_loss(golden_dir):
+    g = np.load(os.path.join(golden_dir, "losses.npz"))
+    from oracle import layout as OL
+    config.set_compute_dtype(torch.float32)
+    disc = ast_amd.Discriminator().to(DEV)
+    disc.load_state_dict(sp.seeded_state_dict(disc.state_dict(), tag="disc"))
+    for B in (8, 16):
+        rng = np.random.default_rng([77, B])
+        style = torch.tensor(rng.standard_normal((B, 256)).astype(np.float32), device=DEV, requires_grad=True)
+        content = torch.tensor(rng.standard_normal((B, 3, 256)).astype(np.float32), device=DEV, requires_grad=True)
+        labels = sp.balanced_labels(B)
+        cls = torch.stack([style[:B // 2].mean(0), style[B // 2:].mean(0)])
+        d_loss, g_loss = ast_amd.adversarial_loss(style, cls, content, disc, labels, False)
+        assert math.isclose(float(d_loss), float(g[f"B{B}_adv_d"]), rel_tol=2e-4)
+        assert math.isclose(float(g_loss), float(g[f"B{B}_adv_g"]), rel_tol=2e-4)
+        gs, gc = torch.autograd.grad(d_loss, [style, content], retain_graph=True)
+        assert rel_err(gs, torch.tensor(g[f"B{B}_adv_d_dstyle"])) < 1e-3
+        assert rel_err(gc, torch.tensor(g[f"B{B}_adv_d_dcontent"])) < 1e-3
+        (gc2,) = torch.autograd.grad(g_loss, [content])
+        assert rel_err(gc2, torch.tensor(g[f"B{B}_adv_g_dcontent"])) < 1e-3
+    # all-zero discriminator -> uniform logits: D = 2.5 ln 2, G = -ln 2 (test_correctness.ipynb cell 9)
+    with torch.no_grad():
+        for p in disc.parameters():
+            p.zero_()
+    e = torch.randn(4, 256, device=DEV)
+    d, gl = ast_amd.adversarial_loss(e, e[:2], e, disc, sp.balanced_labels(4), False)
+    assert math.isclose(float(d), 2.5 * math.log(2), rel_tol=1e-5) and math.isclose(float(gl), -math.log(2), rel_tol=1e-5)
+
+
+def test_stft_frontend(golden_dir):
+    from ast_amd import utilityFunctions as U
+    g = np.load(os.path.join(golden_dir, "frontend.npz"))
+    w = FO.synth_waveform(0, "piano", 4.0)
+    ref = FO.stft(w)
+    st = U.get_STFT(torch.from_numpy(w).to(DEV)[None])
+    assert tuple(st.shape) == (2, 345, 513)
+    scale = float(np.abs(ref).max())
+    assert float((st.cpu() - torch.from_numpy(ref)).abs().max()) < 2e-5 * scale + 1e-5
+    assert np.abs(st[:, ::23, ::17].cpu().numpy() - g["stft_piano0_sub"]).max() < 2e-5 * scale + 2e-5
+    # fused STFT + z-score + sectioning against the oracle pipeline (dataloader.py:94-121 minus CQT)
+    mean = torch.randn(2, 513) * 0.01
+    std = torch.rand(2, 513) + 0.5
+    waves = np.stack([FO.synth_waveform(i, k, 4.0) for i, k in ((0, "piano"), (1, "violin"))])
+    x = U.stft_sections(torch.from_numpy(waves).to(DEV), mean.to(DEV), std.to(DEV), F_total=597)
+    assert tuple(x.shape) == (2, 2, 2, 287, 597)
+    for b in range(2):
+        sec = FO.overlap_windows(FO.normalize(FO.stft(waves[b]), mean.numpy(), std.numpy()))
+        assert np.abs(x[b, :, :, :, :513].cpu().numpy() - sec).max() < 1e-4 * float(np.abs(sec).max())
+    assert float(x[..., 513:].abs().max()) == 0.0
+    # window bookkeeping helpers
+    for s, T, n in zip(g["win_secs"], g["win_frames"], g["win_nsec"]):
+        assert len(U.section_starts(int(T))) == int(n)
+    spec = torch.arange(2 * 345 * 3, dtype=torch.float32, device=DEV).view(2, 345, 3)
+    win = U.get_overlap_windows(spec)
+    assert np.array_equal(win.cpu().numpy(), g["windows_4s"])
+    assert np.allclose(U.sections2spectrogram(win, 345).cpu().numpy(), g["recon_4s"], rtol=1e-6)
+
+
+def test_optimizer_kernels():
+    from ast_amd._lib import lib, check, ptr, stream
+    torch.manual_seed(10)
+    n = 100003
+    p = torch.randn(n, device=DEV); g = torch.randn(n, device=DEV) * 3
+    m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    ref_p = p.clone().cpu().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=1e-3)
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for it in range(3):
+        ref_p.grad = g.cpu().clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        nrm = torch.zeros(1, device=DEV)
+        check(lib().ast_sumsq(ptr(g), n, ptr(nrm), stream()))
+        assert math.isclose(float(nrm), float((g.double() ** 2).sum()), rel_tol=1e-5)
+        check(lib().ast_counter_incr(ptr(step), stream()))
+        check(lib().ast_adam(ptr(p), ptr(g), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0.0, ptr(step), ptr(nrm), 1.0, stream()))
+    assert rel_err(p, ref_p) < 1e-5
