@@ -124,7 +124,6 @@ class Conv2dFn(torch.autograd.Function):
         _igemm(x, pw.wf, pw.bias_ptr_tensor(), y, g)
         ctx.save_for_backward(x)
         ctx.pw, ctx.geom, ctx.args, ctx.bias_grad = pw, g, (k, stride, pad), bias_grad
-        ctx.x_needs_grad = x.requires_grad
         return y
 
     @staticmethod
@@ -139,7 +138,7 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.bias_grad:
             pw.add_bias_grad(dy)
         dx = None
-        if ctx.x_needs_grad:
+        if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             for g in gathers_transposed(N, dy.shape[1], dy.shape[2], pw.Cop, H, W, Cs, k, stride, pad):
                 _igemm(dy, pw.wb, None, dx, g)
@@ -160,7 +159,6 @@ class ConvT2dFn(torch.autograd.Function):
             _igemm(x, pw.wf, b, y, g)
         ctx.save_for_backward(x)
         ctx.pw, ctx.args, ctx.bias_grad = pw, (k, stride, pad, Ho, Wo), bias_grad
-        ctx.x_needs_grad = x.requires_grad
         return y
 
     @staticmethod
@@ -178,7 +176,7 @@ class ConvT2dFn(torch.autograd.Function):
         if ctx.bias_grad:
             pw.add_bias_grad(dy)
         dx = None
-        if ctx.x_needs_grad:
+        if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _igemm(dy, pw.wb, None, dx, g)
         return dx, None, None, None, None, None, None, None
@@ -196,7 +194,7 @@ class LinearFn(torch.autograd.Function):
         y = torch.empty((rows, pw.Cop), dtype=x.dtype, device=x.device)
         _igemm(x, pw.wf, pw.bias_ptr_tensor(), y, g, 2 if relu else 0)
         ctx.save_for_backward(x, y if relu else None)
-        ctx.pw, ctx.relu, ctx.x_needs_grad = pw, relu, x.requires_grad
+        ctx.pw, ctx.relu = pw, relu
         return y
 
     @staticmethod
@@ -215,7 +213,7 @@ class LinearFn(torch.autograd.Function):
         pw.add_weight_grad(dwp, 0)
         pw.add_bias_grad(dy)
         dx = None
-        if ctx.x_needs_grad:
+        if ctx.needs_input_grad[0]:
             gb, _ = gather_direct(rows, 1, 1, pw.Cop, pw.Cip, 1, 1, 0)
             dx = torch.empty_like(x)
             _igemm(dy, pw.wb, None, dx, gb)

@@ -1,0 +1,228 @@
+"""Model-level parity of the HIP-backed drop-in modules against the CPU oracle
+and the golden fixtures captured from the reference (config 1: B=2,S=2 and
+B=4,S=1), forward + backward + mutated buffers + autoregressive decode.
+
+Tolerance (north_star: 1e-3 rel fp32): the f32 path is checked at 1e-3 of the
+tensor scale for outputs/embeddings and loss scalars; gradients at 1e-2 (the
+reference-vs-oracle fp32 re-association noise on gradients is itself 2e-3, see
+tests/test_oracle_golden.py).  The bf16 path (throughput mode) is checked at
+loss-scalar level 2e-2 and relative-L2 5e-2 on outputs.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import ast_amd
+    from ast_amd import config
+from oracle import ast_oracle as O
+from oracle import layout as OL
+from oracle import seeded_params as sp
+
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / max(b.abs().max().item(), 1e-12))
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / max(b.norm().item(), 1e-12))
+
+
+def build_models():
+    ms = {}
+    for tag, ctor in (("style", ast_amd.StyleEncoder), ("content", ast_amd.ContentEncoder),
+                      ("decoder", ast_amd.Decoder), ("disc", ast_amd.Discriminator)):
+        m = ctor()
+        m.load_state_dict(sp.seeded_state_dict(m.state_dict(), tag=tag))
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        ms[tag] = m.to(DEV).train()
+    return ms
+
+
+def hip_step(ms, x, labels):
+    y = x[..., :513]
+    style, cls = ms["style"](x, labels)
+    content = ms["content"](x)
+    out = ms["decoder"](content, cls[labels.to(DEV)], y=y)
+    rec = ast_amd.compute_comprehensive_loss(out, y)
+    nce = ast_amd.infoNCE_loss(style, labels)
+    mar = ast_amd.margin_loss(cls)
+    hs = ast_amd.disentanglement_loss(style, content.mean(1))
+    d_loss, g_loss = ast_amd.adversarial_loss(style, cls, content, ms["disc"], labels, False)
+    total = rec["total_loss"] + nce + mar + hs + g_loss
+    total.backward()
+    return dict(style=style, cls=cls, content=content, out=out, rec=rec, nce=nce, mar=mar, hs=hs, d_loss=d_loss,
+                g_loss=g_loss, total=total)
+
+
+def oracle_step(B, S):
+    sds = {t: OL.seeded_model_state(t) for t in ("style", "content", "decoder", "disc")}
+    cfg = O.Cfg(training=True, p_drop=0.0)
+    x = sp.seeded_input(B, S)
+    labels = sp.balanced_labels(B)
+    y = x[..., :513]
+    style, cls = O.style_encoder_forward(sds["style"], x, labels, cfg)
+    content = O.content_encoder_forward(sds["content"], x, cfg)
+    out = O.decoder_forward(sds["decoder"], content, cls[labels], cfg, y=y)
+    rec = O.comprehensive_loss(out, y)
+    total = (rec["total_loss"] + O.infonce_loss(style, labels) + O.margin_loss(cls)
+             + O.disentanglement_loss(style, content.mean(1))
+             + O.adversarial_loss(sds["disc"], style, cls, content, labels, False)[1])
+    total.backward()
+    return dict(sds=sds, style=style, cls=cls, content=content, out=out, rec=rec, total=total)
+
+
+@pytest.mark.parametrize("name,B,S", [("b2s2", 2, 2), ("b4s1", 4, 1)])
+def test_full_step_f32_vs_golden_and_oracle(golden_dir, name, B, S):
+    config.set_compute_dtype(torch.float32)
+    g = np.load(os.path.join(golden_dir, f"model_{name}.npz"))
+    ms = build_models()
+    x = sp.seeded_input(B, S).to(DEV)
+    labels = sp.balanced_labels(B)
+    r = hip_step(ms, x, labels)
+    # ---- forward against the reference's golden vectors (1e-3 of scale)
+    assert rel_err(r["style"], g["style_emb"]) < 1e-3
+    assert rel_err(r["cls"], g["class_emb"]) < 1e-3
+    assert rel_err(r["content"], g["content_emb"]) < 1e-3
+    out = r["out"].detach()
+    assert rel_err(out[:, :, :, ::11, ::13], g["out_sub"]) < 1e-3
+    assert rel_err(out.abs().sum(dim=(3, 4)), g["out_abs_sum"]) < 1e-3
+    for k in ("total_loss", "mse_loss", "mag_loss", "phase_loss", "temporal_loss", "spectral_loss"):
+        assert math.isclose(float(r["rec"][k]), float(g["rec_" + k]), rel_tol=1e-3, abs_tol=1e-6), k
+    for key, val in (("infonce", r["nce"]), ("margin", r["mar"]), ("hsic", r["hs"]), ("adv_d", r["d_loss"]),
+                     ("adv_g", r["g_loss"]), ("total", r["total"])):
+        assert math.isclose(float(val), float(g["loss_" + key]), rel_tol=1e-3, abs_tol=1e-6), key
+    # ---- buffers mutated by the training forward
+    st, dec = ms["style"], ms["decoder"]
+    assert rel_err(st.cnn.net[0].bn1.running_mean, g["bn_rm_style_b0_bn1"]) < 1e-3
+    assert rel_err(st.cnn.net[0].bn1.running_var, g["bn_rv_style_b0_bn1"]) < 1e-3
+    assert rel_err(dec.conv_encoder[1].running_mean, g["bn_rm_dec_ce1"]) < 1e-3
+    assert rel_err(dec.conv_decoder[10].running_var, g["bn_rv_dec_cd10"]) < 1e-3
+    assert rel_err(st.cnn.net[0].conv1.weight_u, g["sn_u_style_b0_conv1"]) < 1e-4
+    assert rel_err(st.cnn.net[5].conv2.weight_v, g["sn_v_style_b5_conv2"]) < 1e-4
+    assert rel_err(dec.conv_decoder[3].weight_u, g["sn_u_dec_cd3"]) < 1e-4
+    assert rel_err(dec.conv_decoder[3].weight_v, g["sn_v_dec_cd3"]) < 1e-4
+    assert int(st.cnn.net[0].bn1.num_batches_tracked) == 1
+    # ---- gradients: per-parameter norms + raw slices from the reference
+    for tag in ("style", "content", "decoder"):
+        params = dict(ms[tag].named_parameters())
+        bad = []
+        for k, v in zip(g[f"gradnorm_keys_{tag}"], g[f"gradnorm_vals_{tag}"]):
+            k = str(k)
+            gr = params[k].grad
+            got = 0.0 if gr is None else float(gr.norm())
+            if v < 1e-3:          # incl. biases in front of a norm layer: identically 0 here, rounding noise there
+                ok = got < 2e-3
+            else:
+                ok = math.isclose(got, v, rel_tol=1e-2)
+            if not ok:
+                bad.append((k, got, float(v)))
+        assert not bad, (tag, bad[:8])
+    assert rel_err(st.cnn.net[0].conv1.weight_orig.grad, g["grad_style_conv1_0"]) < 1e-2
+    assert rel_err(st.cnn.proj.weight.grad[:8], g["grad_style_proj_w"]) < 1e-2
+    assert rel_err(ms["content"].cnn[5].conv2.weight_orig.grad[:4, :4], g["grad_content_b5_conv2"]) < 1e-2
+    assert rel_err(dec.conv_decoder[3].weight_orig.grad[:8, :8], g["grad_dec_convT3"]) < 1e-2
+    assert rel_err(dec.start_token.grad, g["grad_dec_start_token"]) < 1e-2
+    # ---- and against the on-box oracle, full tensors
+    o = oracle_step(B, S)
+    assert rel_err(r["out"], o["out"]) < 1e-3
+    assert math.isclose(float(r["total"]), float(o["total"]), rel_tol=1e-3)
+    for tag in ("style", "content", "decoder"):
+        worst = 0.0
+        for k, p in ms[tag].named_parameters():
+            ref = o["sds"][tag][k].grad
+            if ref is None or p.grad is None or float(ref.norm()) < 1e-3:
+                continue
+            worst = max(worst, rel_l2(p.grad, ref))
+        assert worst < 1e-2, (tag, worst)
+
+    if name == "b2s2":   # eval-mode autoregressive decode (config 4 plumbing), after the one training step
+        gi = np.load(os.path.join(golden_dir, "infer_b2s2.npz"))
+        for m in ms.values():
+            m.eval()
+        with torch.no_grad():
+            se, ce_ = ms["style"](x, labels)
+            co = ms["content"](x)
+            ar = ms["decoder"](co, ce_[labels.to(DEV)])
+        assert rel_err(se, gi["style_emb"]) < 1e-3 and rel_err(co, gi["content_emb"]) < 1e-3
+        assert rel_err(ar[:, :, :, ::11, ::13], gi["out_sub"]) < 1e-3
+
+
+def _surrogate(style, content, out, dev):
+    """Smooth (linear) functional of the three model outputs with fixed random weights."""
+    gen = torch.Generator().manual_seed(5)
+    ws = torch.randn(style.shape, generator=gen).to(dev)
+    wc = torch.randn(content.shape, generator=gen).to(dev)
+    wo = torch.randn(out.shape, generator=gen).to(dev)
+    return (style * ws).sum() + (content * wc).sum() + (out * wo).sum() / 50.0
+
+
+def test_full_step_bf16_vs_oracle():
+    """bf16 MFMA path (throughput mode).  Forward and loss scalars are compared on the real
+    losses.  Gradients are compared on a smooth surrogate: the reference's wrapped-phase term
+    (new_decoder.py:377-383) is discontinuous at +-pi and weights by 1/|z|^2, so it amplifies
+    the 0.3-0.9 % forward rounding of bf16 into O(20 %) gradient changes that say nothing about
+    the backward kernels (the f32 test above covers the real loss end to end)."""
+    config.set_compute_dtype(torch.bfloat16)
+    try:
+        B, S = 2, 2
+        ms = build_models()
+        x = sp.seeded_input(B, S).to(DEV)
+        labels = sp.balanced_labels(B)
+        y = x[..., :513]
+        style, cls = ms["style"](x, labels)
+        content = ms["content"](x)
+        out = ms["decoder"](content, cls[labels.to(DEV)], y=y)
+        rec = ast_amd.compute_comprehensive_loss(out, y)
+        _surrogate(style, content, out, DEV).backward()
+
+        sds = {t: OL.seeded_model_state(t) for t in ("style", "content", "decoder")}
+        cfg = O.Cfg(training=True, p_drop=0.0)
+        xc = x.cpu()
+        so, co_ = O.style_encoder_forward(sds["style"], xc, labels, cfg)
+        cn = O.content_encoder_forward(sds["content"], xc, cfg)
+        oo = O.decoder_forward(sds["decoder"], cn, co_[labels], cfg, y=xc[..., :513])
+        reco = O.comprehensive_loss(oo, xc[..., :513])
+        _surrogate(so, cn, oo, "cpu").backward()
+
+        assert rel_l2(out, oo) < 3e-2
+        assert rel_l2(style, so) < 2e-2 and rel_l2(content, cn) < 2e-2
+        for k in ("total_loss", "mse_loss", "mag_loss", "phase_loss", "temporal_loss", "spectral_loss"):
+            assert math.isclose(float(rec[k]), float(reco[k]), rel_tol=2e-2), k
+        for tag in ("style", "content", "decoder"):
+            num = den = 0.0
+            for k, p in ms[tag].named_parameters():
+                ref = sds[tag][k].grad
+                if ref is None or p.grad is None:
+                    continue
+                num += float((p.grad.double().cpu() - ref.double()).pow(2).sum())
+                den += float(ref.double().pow(2).sum())
+            assert math.sqrt(num / den) < 0.15, (tag, math.sqrt(num / den))   # bf16 storage of activations AND gradients, 12 conv+BN layers each way
+    finally:
+        config.set_compute_dtype(torch.float32)
+
+
+def test_error_surface():
+    config.set_compute_dtype(torch.float32)
+    dec = ast_amd.Decoder().to(DEV).train()
+    c = torch.randn(2, 2, 256, device=DEV)
+    with pytest.raises(ValueError):
+        dec(c, torch.randn(2, 256, device=DEV), y=torch.randn(2, 2, 287, 513, device=DEV))
+    # fresh decoder outputs exactly zero (new_decoder.py:134-143)
+    out = dec(c, torch.randn(2, 256, device=DEV), y=torch.randn(2, 2, 2, 287, 513, device=DEV))
+    assert out.shape == (2, 2, 2, 287, 513) and float(out.abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ast_amd.StyleEncoder()(torch.randn(1, 1, 2, 287, 597))        # CPU tensors: no fallback
