@@ -28,6 +28,7 @@ class WeightBank:
         self.specs = []
         self.entries: list[PackedWeight] = []
         self._key = None
+        self.hold = False     # True: packed images are current (several forwards between optimiser steps)
 
     def add(self, weight, kind, dtype_fn, u=None, v=None, bias=None, rows=None):
         """kind: 'conv' (Co,Ci,k,k) | 'convT' (Ci,Co,k,k) | 'linear' (Co,Ci); rows=(r0,r1) selects output rows
@@ -84,6 +85,8 @@ class WeightBank:
         self._key = self._signature()
 
     def prepare(self, training: bool):
+        if self.hold:
+            return
         if self._key != self._signature():
             self._build()
         d = self.d_train if training else self.d_eval

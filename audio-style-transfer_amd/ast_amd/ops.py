@@ -68,8 +68,55 @@ def gathers_transposed(N, Hs, Ws, Cs, Hd, Wd, Cd, k, stride, pad):
     return tuple(out)
 
 
+PROFILE = None     # bench.py sets this to a list: (kernel config, algorithmic flops, bytes, start event, end event)
+
+
+def _gemm_cost(g, esize, wgrad=False):
+    """Algorithmic work of one launch: 2*M*N*K flops; operands + result once (HBM)."""
+    M = g.N * g.Hm * g.Wm
+    K = g.ntaps * g.Cs
+    flops = 2.0 * M * g.Cd * K
+    if wgrad:
+        nbytes = (M * g.Cd + g.N * g.Hs * g.Ws * g.Cs) * esize + g.Cd * K * 4
+    else:
+        src_pix = min(g.N * g.Hs * g.Ws, M * max(g.ntaps, 1))
+        nbytes = (src_pix * g.Cs + M * g.Cd + g.Cd * K) * esize
+    return flops, nbytes
+
+
+def _igemm_config(g, M):
+    """Mirrors the tile selection in csrc/igemm.hip:ast_igemm (for reporting only)."""
+    t128 = ((M + 127) // 128) * ((g.Cd + 127) // 128)
+    if g.Cd > 64:
+        return "128x128" if t128 >= 384 else "64x64"
+    if g.Cd > 32:
+        return "128x64" if M >= 128 * 512 else "64x64"
+    if g.Cd > 16:
+        return "256x32" if M >= 256 * 512 else "64x32"
+    return "256x16" if M >= 256 * 512 else "64x16"
+
+
 def _igemm(src, wgt, bias, dst, g, flags=0):
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().ast_igemm(ptr(src), ptr(wgt), ptr(bias), ptr(dst), g, dcode(src.dtype), flags, stream()), "ast_igemm")
+    if PROFILE is not None:
+        e1.record()
+        fl, by = _gemm_cost(g, src.element_size())
+        dt = "bf16" if src.dtype == torch.bfloat16 else "f32"
+        PROFILE.append((f"igemm_kernel<{dt},{_igemm_config(g, g.N * g.Hm * g.Wm)}>", fl, by, e0, e1))
+
+
+def _wgrad(dy, src, dwp, g):
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib().ast_wgrad(ptr(dy), ptr(src), ptr(dwp), g, dcode(src.dtype), stream()), "ast_wgrad")
+    if PROFILE is not None:
+        e1.record()
+        fl, by = _gemm_cost(g, src.element_size(), wgrad=True)
+        PROFILE.append((f"wgrad_kernel<{'bf16' if src.dtype == torch.bfloat16 else 'f32'}>", fl, by, e0, e1))
 
 
 def acc_grad(p: torch.Tensor) -> torch.Tensor:
@@ -133,7 +180,7 @@ class Conv2dFn(torch.autograd.Function):
         dy = dy.contiguous()
         N, H, W, Cs = x.shape
         dwp = torch.zeros((pw.Cop, pw.KK, pw.Cip), dtype=torch.float32, device=x.device)
-        check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(dwp), ctx.geom, dcode(x.dtype), stream()), "ast_wgrad")
+        _wgrad(dy, x, dwp, ctx.geom)
         pw.add_weight_grad(dwp, 0)
         if ctx.bias_grad:
             pw.add_bias_grad(dy)
@@ -171,7 +218,7 @@ class ConvT2dFn(torch.autograd.Function):
         g, (Hx, Wx) = gather_direct(N, Ho, Wo, pw.Cop, Cs, k, stride, pad)
         assert (Hx, Wx) == (H, W), "ConvTranspose2d geometry mismatch"
         dwp = torch.zeros((pw.Cip, pw.KK, pw.Cop), dtype=torch.float32, device=x.device)
-        check(lib().ast_wgrad(ptr(x), ptr(dy), ptr(dwp), g, dcode(x.dtype), stream()), "ast_wgrad")
+        _wgrad(x, dy, dwp, g)
         pw.add_weight_grad(dwp, 1)
         if ctx.bias_grad:
             pw.add_bias_grad(dy)
@@ -209,7 +256,7 @@ class LinearFn(torch.autograd.Function):
             dy = dz
         g, _ = gather_direct(rows, 1, 1, pw.Cip, pw.Cop, 1, 1, 0)
         dwp = torch.zeros((pw.Cop, 1, pw.Cip), dtype=torch.float32, device=x.device)
-        check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(dwp), g, dcode(x.dtype), stream()), "ast_wgrad")
+        _wgrad(dy, x, dwp, g)
         pw.add_weight_grad(dwp, 0)
         pw.add_bias_grad(dy)
         dx = None

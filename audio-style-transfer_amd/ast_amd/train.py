@@ -1,0 +1,226 @@
+"""Train-step harness: the step `train2.ipynb` runs (reconstructed -- the notebook
+is not in the reference checkout) over the drop-in modules.
+
+    encoders -> D phase (adversarial_loss on detached embeddings, Adam on D)
+             -> G phase (decoder teacher forcing + recon/InfoNCE/margin/HSIC/
+                adversarial-generator losses, grad-norm clip, Adam on encoders+decoder)
+
+MI355X-first choices: parameters and gradients of each optimiser group live in
+ONE flat f32 buffer (views handed to the modules), so zero_grad is one memset,
+clipping is one reduction launch, Adam is one launch and the data-parallel
+exchange is one RCCL all-reduce per group; the whole step (hundreds of small
+launches) is captured into a hipGraph and replayed.
+"""
+from __future__ import annotations
+
+import dataclasses
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import config, ops
+from ._lib import check, lib, ptr, stream
+from .content_encoder import ContentEncoder
+from .discriminator import Discriminator
+from .losses import adversarial_loss, disentanglement_loss, infoNCE_loss, margin_loss
+from .new_decoder import Decoder, compute_comprehensive_loss
+from .style_encoder import StyleEncoder, _module_bank, initialize_weights
+
+
+@dataclasses.dataclass
+class TrainConfig:
+    lr_g: float = 1e-4
+    lr_d: float = 1e-4
+    betas: tuple = (0.9, 0.999)
+    eps: float = 1e-8
+    max_grad_norm: float = 1.0
+    # loss weights (unknown in the reference; 1.0 = plain sum) and curriculum gates (README.md:144-150)
+    w_rec: float = 1.0
+    w_nce: float = 1.0
+    w_margin: float = 1.0
+    w_hsic: float = 1.0
+    w_adv: float = 1.0
+    use_hsic: bool = True
+    use_nce: bool = True
+    use_adv: bool = True
+    use_graph: bool = True
+    dropout: bool = True          # nn.Dropout(0.1) as constructed by the reference
+
+
+def curriculum_gates(progress: float):
+    """README.md:144-150: 0-20 % recon only, 20-40 % + disentanglement, 40-60 % + contrastive, 60-100 % + adversarial."""
+    return dict(use_hsic=progress >= 0.2, use_nce=progress >= 0.4, use_adv=progress >= 0.6)
+
+
+class FlatGroup:
+    """Parameters of several modules re-seated as views of one flat buffer, with a flat
+    gradient buffer, Adam moments and device-side step counter."""
+
+    def __init__(self, modules, device):
+        self.params = [p for m in modules for p in m.parameters()]
+        n = sum(p.numel() for p in self.params)
+        self.n = n
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=device)
+        self.m = torch.zeros(n, dtype=torch.float32, device=device)
+        self.v = torch.zeros(n, dtype=torch.float32, device=device)
+        self.step = torch.zeros(1, dtype=torch.int64, device=device)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=device)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = self.flat_p[off:off + k].view(p.shape)
+            p.grad = self.flat_g[off:off + k].view(p.shape)
+            off += k
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def all_reduce(self, world):
+        from .parallel import allreduce_mean_
+
+        def scale(t, s):
+            check(lib().ast_scale(ptr(t), None, s, ptr(t), t.numel(), 0, stream()), "ast_scale")
+        allreduce_mean_(self.flat_g, world, scale)
+
+    def adam(self, lr, betas, eps, max_norm):
+        self.gnorm_sq.zero_()
+        check(lib().ast_sumsq(ptr(self.flat_g), self.n, ptr(self.gnorm_sq), stream()), "ast_sumsq")
+        check(lib().ast_counter_incr(ptr(self.step), stream()), "ast_counter_incr")
+        check(lib().ast_adam(ptr(self.flat_p), ptr(self.flat_g), ptr(self.m), ptr(self.v), self.n, lr, betas[0], betas[1], eps,
+                             0.0, ptr(self.step), ptr(self.gnorm_sq) if max_norm > 0 else None, max_norm, stream()), "ast_adam")
+
+
+class Trainer:
+    def __init__(self, cfg: TrainConfig = None, device="cuda:0", rank=0, world=1, seed=1234, init="reference"):
+        self.cfg = cfg or TrainConfig()
+        self.device = torch.device(device)
+        self.rank, self.world = rank, world
+        torch.manual_seed(seed)                      # identical replicas on every rank
+        self.style, self.content = StyleEncoder(), ContentEncoder()
+        self.decoder, self.disc = Decoder(), Discriminator()
+        if init == "reference":
+            # a freshly built reference decoder has all BN/LN gammas = 0 and outputs 0:
+            # give the gammas their conventional value 1 so the step does real work
+            with torch.no_grad():
+                for name, p in self.decoder.named_parameters():
+                    if p.dim() == 1 and "weight" in name:
+                        p.fill_(1.0)
+        if not self.cfg.dropout:
+            for m in (self.style, self.content, self.decoder):
+                for mod in m.modules():
+                    if isinstance(mod, torch.nn.Dropout):
+                        mod.p = 0.0
+                    if isinstance(mod, torch.nn.MultiheadAttention):
+                        mod.dropout = 0.0
+        for m in (self.style, self.content, self.decoder, self.disc):
+            m.to(self.device).train()
+        self.G = FlatGroup([self.style, self.content, self.decoder], self.device)
+        self.D = FlatGroup([self.disc], self.device)
+        self._graphs = {}
+        self._static = None
+        self.losses = {}
+
+    # ------------------------------------------------------------------ one eager step
+    def _forward_backward(self, x, labels_host):
+        c = self.cfg
+        self.G.zero_grad()
+        self.D.zero_grad()
+        if ops._DropState.counter is None or ops._DropState.counter.device != self.device:
+            ops._DropState.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        check(lib().ast_counter_incr(ptr(ops._DropState.counter), stream()), "ast_counter_incr")
+        y = x[..., :513]
+        style_emb, class_emb = self.style(x, labels_host)
+        content_emb = self.content(x)
+        # ---- D phase (losses.py:69-79 compute_for_discriminator=True)
+        bank_d = _module_bank(self.disc)
+        bank_d.prepare(True)
+        bank_d.hold = True
+        d_loss, _ = adversarial_loss(style_emb.detach(), class_emb.detach(), content_emb.detach(), self.disc, labels_host, True)
+        d_loss.backward()
+        bank_d.hold = False
+        return y, style_emb, class_emb, content_emb, d_loss
+
+    def _g_phase(self, x, y, labels_host, style_emb, class_emb, content_emb):
+        c = self.cfg
+        idx = ops.const_tensor(tuple(int(v) for v in labels_host.tolist()), torch.long, self.device)
+        out = self.decoder(content_emb, class_emb.index_select(0, idx), y=y)
+        rec = compute_comprehensive_loss(out, y)
+        total = c.w_rec * rec["total_loss"]
+        parts = {"rec": rec["total_loss"].detach()}
+        total = total + c.w_margin * margin_loss(class_emb)
+        if c.use_nce:
+            nce = infoNCE_loss(style_emb, labels_host)
+            total = total + c.w_nce * nce
+            parts["nce"] = nce.detach()
+        if c.use_hsic:
+            hs = disentanglement_loss(style_emb, content_emb.mean(dim=1))
+            total = total + c.w_hsic * hs
+            parts["hsic"] = hs.detach()
+        if c.use_adv:
+            bank_d = _module_bank(self.disc)
+            bank_d.prepare(True)          # D weights changed in the D phase
+            bank_d.hold = True
+            _, g_adv = adversarial_loss(style_emb, class_emb, content_emb, self.disc, labels_host, False)
+            bank_d.hold = False
+            total = total + c.w_adv * g_adv
+            parts["adv_g"] = g_adv.detach()
+        total.backward()
+        parts["total"] = total.detach()
+        return parts
+
+    def _step_body(self, x, labels_host):
+        c = self.cfg
+        y, style_emb, class_emb, content_emb, d_loss = self._forward_backward(x, labels_host)
+        self.D.all_reduce(self.world)
+        self.D.adam(c.lr_d, c.betas, c.eps, c.max_grad_norm)
+        self.D.zero_grad()
+        parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb)
+        self.G.all_reduce(self.world)
+        self.G.adam(c.lr_g, c.betas, c.eps, c.max_grad_norm)
+        parts["adv_d"] = d_loss.detach()
+        return parts
+
+    # ------------------------------------------------------------------ public API
+    def step(self, x: torch.Tensor, labels_host: torch.Tensor):
+        """x: (B,S,2,287,597) f32 on the device; labels on the HOST (balanced [0]*B/2+[1]*B/2 as
+        dataloader.py:143-146 builds them).  Returns a dict of detached device scalars."""
+        assert not labels_host.is_cuda, "pass labels on the host: avoids a device sync per step"
+        use_graph = self.cfg.use_graph and self.world == 1
+        if not use_graph:
+            self.losses = self._step_body(x, labels_host)
+            return self.losses
+        key = (tuple(x.shape), tuple(labels_host.tolist()), config.compute_dtype, self.cfg.use_nce, self.cfg.use_hsic, self.cfg.use_adv)
+        if key not in self._graphs:
+            self._capture(key, x, labels_host)
+        gph, static_x, outs = self._graphs[key]
+        if static_x.data_ptr() != x.data_ptr():
+            static_x.copy_(x)
+        gph.replay()
+        self.losses = outs
+        return outs
+
+    def _capture(self, key, x, labels_host):
+        static_x = x.clone()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                       # warm-up: builds weight banks, const tensors, caches
+                self._step_body(static_x, labels_host)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gph):
+            outs = self._step_body(static_x, labels_host)
+        self._graphs[key] = (gph, static_x, outs)
+
+
+def synthetic_batch(B, S, device, seed=1000):
+    """Model-ready synthetic batch: x ~ N(0,1) (what z-scored spectrograms look like and what the
+    reference's own smoke tests feed, test_correctness.ipynb cell 6), balanced labels."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, S, 2, 287, 597), generator=g, dtype=torch.float32)
+    labels = torch.cat([torch.zeros(B // 2, dtype=torch.long), torch.ones(B - B // 2, dtype=torch.long)])
+    return x.to(device), labels
