@@ -34,8 +34,11 @@ class WeightDesc(C.Structure):
 
 _SIGS = {
     "ast_version": ([], i32),
-    "ast_igemm": ([vp, vp, vp, vp, C.POINTER(Gather), i32, i32, vp], i32),
+    "ast_igemm": ([vp, vp, vp, vp, C.POINTER(Gather), i32, i32, vp, C.c_long, vp], i32),
+    "ast_igemm_ws_floats": ([C.POINTER(Gather), i32], C.c_long),
     "ast_wgrad": ([vp, vp, vp, C.POINTER(Gather), i32, vp], i32),
+    "ast_skinny_gemm": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "ast_linear_wgrad": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "ast_nchw_to_nhwc": ([vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, i32, vp], i32),
     "ast_nhwc_to_nchw": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "ast_cast": ([vp, i32, vp, i32, i64, vp], i32),

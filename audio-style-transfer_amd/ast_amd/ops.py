@@ -96,11 +96,27 @@ def _igemm_config(g, M):
     return "256x16" if M >= 256 * 512 else "64x16"
 
 
+_ws_cache = {}
+
+
+def _ws_need(g, dt):
+    key = (id(g), dt)          # Gather objects are interned by the lru-cached geometry builders
+    v = _ws_cache.get(key)
+    if v is None:
+        v = int(lib().ast_igemm_ws_floats(g, dt))
+        if v < 0:
+            check(-1, "ast_igemm_ws_floats")
+        _ws_cache[key] = v
+    return v
+
+
 def _igemm(src, wgt, bias, dst, g, flags=0):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib().ast_igemm(ptr(src), ptr(wgt), ptr(bias), ptr(dst), g, dcode(src.dtype), flags, stream()), "ast_igemm")
+    need = _ws_need(g, dcode(src.dtype))
+    ws = torch.empty(need, dtype=torch.float32, device=src.device) if need > 0 else None
+    check(lib().ast_igemm(ptr(src), ptr(wgt), ptr(bias), ptr(dst), g, dcode(src.dtype), flags, ptr(ws), need, stream()), "ast_igemm")
     if PROFILE is not None:
         e1.record()
         fl, by = _gemm_cost(g, src.element_size())
@@ -229,17 +245,30 @@ class ConvT2dFn(torch.autograd.Function):
         return dx, None, None, None, None, None, None, None
 
 
+SKINNY_MAX_ROWS = 64
+
+
 class LinearFn(torch.autograd.Function):
-    """nn.Linear on (rows, in) f32 token tensors; optional fused ReLU."""
+    """nn.Linear on (rows, in) f32 token tensors; optional fused ReLU.  rows <= 64 (every linear of
+    the model at B=8: B*(S+1) <= 40 token rows) takes the wave-per-column path of csrc/skinny.hip and
+    writes dW/db straight into the parameter gradients; larger row counts use the MFMA igemm."""
 
     @staticmethod
     def forward(ctx, x, weight, pw: PackedWeight, relu):
         x = x.contiguous()
         rows = x.shape[0]
         assert x.shape[1] == pw.Cip and x.dtype == pw.dtype, (x.shape, pw.Cip, x.dtype, pw.dtype)
-        g, _ = gather_direct(rows, 1, 1, pw.Cip, pw.Cop, 1, 1, 0)
+        ctx.skinny = rows <= SKINNY_MAX_ROWS and pw.KK == 1 and pw.u is None and pw.Ci == pw.Cip
         y = torch.empty((rows, pw.Cop), dtype=x.dtype, device=x.device)
-        _igemm(x, pw.wf, pw.bias_ptr_tensor(), y, g, 2 if relu else 0)
+        if ctx.skinny:
+            if pw.Cop != pw.Co:
+                y.zero_()
+            b = None if pw.bias is None else pw.bias.data_ptr() + 4 * pw.b_off
+            check(lib().ast_skinny_gemm(ptr(x), pw.weight.data_ptr() + 4 * pw.w_off, b, ptr(y), rows, pw.Co, pw.Ci, pw.s_co,
+                                        pw.Cop, int(relu), stream()), "ast_skinny_gemm")
+        else:
+            g, _ = gather_direct(rows, 1, 1, pw.Cip, pw.Cop, 1, 1, 0)
+            _igemm(x, pw.wf, pw.bias_ptr_tensor(), y, g, 2 if relu else 0)
         ctx.save_for_backward(x, y if relu else None)
         ctx.pw, ctx.relu = pw, relu
         return y
@@ -254,12 +283,22 @@ class LinearFn(torch.autograd.Function):
             dz = torch.empty_like(dy)
             check(lib().ast_relu_bwd(ptr(dy), ptr(y), ptr(dz), dy.numel(), dcode(dy.dtype), stream()), "ast_relu_bwd")
             dy = dz
+        dx = None
+        if ctx.skinny:
+            gw = acc_grad(pw.weight)
+            gb = None if pw.bias is None else acc_grad(pw.bias).data_ptr() + 4 * pw.b_off
+            check(lib().ast_linear_wgrad(ptr(dy), ptr(x), gw.data_ptr() + 4 * pw.w_off, gb, rows, pw.Co, pw.Ci, pw.Cop, pw.s_co,
+                                         stream()), "ast_linear_wgrad")
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)       # dx[m][k] = sum_n dy[m][n] Wt[k][n], Wt = packed [Ci][Cop]
+                check(lib().ast_skinny_gemm(ptr(dy), ptr(pw.wb), None, ptr(dx), rows, pw.Ci, pw.Cop, pw.Cop, pw.Cip, 0, stream()),
+                      "ast_skinny_gemm")
+            return dx, None, None, None
         g, _ = gather_direct(rows, 1, 1, pw.Cip, pw.Cop, 1, 1, 0)
         dwp = torch.zeros((pw.Cop, 1, pw.Cip), dtype=torch.float32, device=x.device)
         _wgrad(dy, x, dwp, g)
         pw.add_weight_grad(dwp, 0)
         pw.add_bias_grad(dy)
-        dx = None
         if ctx.needs_input_grad[0]:
             gb, _ = gather_direct(rows, 1, 1, pw.Cop, pw.Cip, 1, 1, 0)
             dx = torch.empty_like(x)

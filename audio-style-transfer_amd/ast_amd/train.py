@@ -59,9 +59,9 @@ class FlatGroup:
 
     def __init__(self, modules, device):
         self.params = [p for m in modules for p in m.parameters()]
-        n = sum(p.numel() for p in self.params)
+        n = sum((p.numel() + 3) // 4 * 4 for p in self.params)      # every view starts 16-byte aligned (float4 kernels)
         self.n = n
-        self.flat_p = torch.empty(n, dtype=torch.float32, device=device)
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=device)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=device)
         self.m = torch.zeros(n, dtype=torch.float32, device=device)
         self.v = torch.zeros(n, dtype=torch.float32, device=device)
@@ -73,7 +73,7 @@ class FlatGroup:
             self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
             p.data = self.flat_p[off:off + k].view(p.shape)
             p.grad = self.flat_g[off:off + k].view(p.shape)
-            off += k
+            off += (k + 3) // 4 * 4
 
     def zero_grad(self):
         self.flat_g.zero_()

@@ -17,7 +17,6 @@
 
 namespace {
 
-constexpr int ROWB = 80;  // LDS row pitch: 64 B of data + 16 B pad (bank spread for ds_read_b128)
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -36,48 +35,73 @@ template <> struct Mma<float> {
   }
 };
 
-struct RowPix { int pixbase, hs0, ws0; bool valid; };
+struct RowPix { int off, hs0, ws0; bool valid; };
 
 __device__ __forceinline__ void decode_tap(int tp, int& dh, int& dw, int& wt) {
   dh = (tp & 255) - 64; dw = ((tp >> 8) & 255) - 64; wt = tp >> 16;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+// Epilogue helper: lane owns 4 consecutive channels of one destination pixel.
+template <typename T>
+__device__ __forceinline__ void store4(T* p, float (&v)[4], bool accumulate, bool relu) {
+  if constexpr (sizeof(T) == 4) {
+    f32x4* q = reinterpret_cast<f32x4*>(p);
+    if (accumulate) { const f32x4 o = *q; for (int r = 0; r < 4; ++r) v[r] += o[r]; }
+    if (relu) for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    *q = f32x4{v[0], v[1], v[2], v[3]};
+  } else {
+    bf16x4* q = reinterpret_cast<bf16x4*>(p);
+    if (accumulate) { const bf16x4 o = *q; for (int r = 0; r < 4; ++r) v[r] += (float)o[r]; }
+    if (relu) for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    *q = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+  }
+}
+
+// KCH = 16-byte chunks per row per K tile (4 -> 64 B, 8 -> 128 B): one barrier per tile.
+// grid.z = split-K slices; with more than one slice the f32 partial tiles are added into `ws`
+// ([M][Cd]) with atomics and splitk_finish_kernel applies bias / accumulate / ReLU / cast.
+template <typename T, int BM, int BN, int WM, int WN, int KCH>
 __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, const T* __restrict__ wgt,
                                                      const float* __restrict__ bias, T* __restrict__ dst,
-                                                     const ast_gather_t g, const int M, const int flags) {
+                                                     const ast_gather_t g, const int M, const int flags,
+                                                     float* __restrict__ ws, const int kt_per_split, const int cpc_shift) {
   constexpr int E = 16 / sizeof(T);
+  constexpr int RB = KCH * 16 + 16;          // LDS row pitch: data + 16 B pad (bank spread for ds_read_b128)
+  constexpr int RPP = 256 / KCH;             // rows staged per pass
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
-  constexpr int AI = BM / 64, BI = (BN + 63) / 64;
-  static_assert(WM * WN == 4 && BM % 64 == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile");
+  constexpr int AI = BM / RPP, BI = (BN + RPP - 1) / RPP;
+  static_assert(WM * WN == 4 && BM % RPP == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile");
   using frag = typename Mma<T>::frag;
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * ROWB];
-  __shared__ int taptab[AST_MAX_TAPS];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // 2 * (BM + BN) * RB, then 16 ints
+  int* taptab = reinterpret_cast<int*>(lds + 2 * (BM + BN) * RB);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int cc = tid & 3, r0 = tid >> 2;
+  const int cc = tid % KCH, r0 = tid / KCH;
   const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
   const int cpc = g.Cs / E;
   const int nchunks = g.ntaps * cpc;
-  const int KT = (nchunks + 3) >> 2;
+  const int KT = (nchunks + KCH - 1) / KCH;
+  const int kt0 = blockIdx.z * kt_per_split, kt1 = min(KT, kt0 + kt_per_split);
   const int HWm = g.Hm * g.Wm;
 
-  if (tid < AST_MAX_TAPS) taptab[tid] = g.tap[tid];
+#pragma unroll
+  for (int t = 0; t < AST_MAX_TAPS; ++t)
+    if (tid == t) taptab[t] = g.tap[t];          // static index: a dynamic one would spill the by-value struct to scratch
 
   RowPix rp[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    const int m = bm0 + r0 + 64 * i;
+    const int m = bm0 + r0 + RPP * i;
     rp[i].valid = m < M;
     const int mm = rp[i].valid ? m : 0;
     const int n = mm / HWm, rem = mm - n * HWm;
     const int hm = rem / g.Wm, wq = rem - hm * g.Wm;
-    rp[i].pixbase = n * g.Hs * g.Ws;
     rp[i].hs0 = hm * g.sh + g.oh;
     rp[i].ws0 = wq * g.sw + g.ow;
+    rp[i].off = ((n * g.Hs + rp[i].hs0) * g.Ws + rp[i].ws0) * g.Cs;
   }
   __syncthreads();
 
@@ -88,68 +112,89 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   uint4 areg[AI], breg[BI];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
-  auto load_tile = [&](int kt) {
-    const int kc = kt * 4 + cc;
+  auto load_tile = [&](int kt) __attribute__((always_inline)) {
+    const int kc = kt * KCH + cc;
     const bool kval = kc < nchunks;
-    const int t = kval ? kc / cpc : 0;
+    const int t = kval ? (cpc_shift >= 0 ? (kc >> cpc_shift) : kc / cpc) : 0;
     const int c0 = (kc - t * cpc) * E;
     int dh, dw, wt;
     decode_tap(taptab[t], dh, dw, wt);
+    const int delta = (dh * g.Ws + dw) * g.Cs + c0;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int hs = rp[i].hs0 + dh, ws = rp[i].ws0 + dw;
-      const bool ok = kval && rp[i].valid && (unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws;
-      areg[i] = ok ? *reinterpret_cast<const uint4*>(src + ((size_t)(rp[i].pixbase + hs * g.Ws + ws) * g.Cs + c0)) : zero4;
+      const bool ok = kval && rp[i].valid && (unsigned)(rp[i].hs0 + dh) < (unsigned)g.Hs &&
+                      (unsigned)(rp[i].ws0 + dw) < (unsigned)g.Ws;
+      // always a valid global address (element 0 when masked) + value select: a conditional
+      // dereference compiles to a FLAT load through a pointer select (ties vmcnt to lgkmcnt)
+      const uint4 v = *reinterpret_cast<const uint4*>(src + (ok ? rp[i].off + delta : 0));
+      areg[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
     }
+    const int woff = wt * g.Cs + c0;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int row = r0 + 64 * i, co = bn0 + row;
+      const int row = r0 + RPP * i, co = bn0 + row;
       const bool ok = kval && row < BN && co < g.Cd;
-      breg[i] = ok ? *reinterpret_cast<const uint4*>(wgt + (((size_t)co * g.wtaps + wt) * g.Cs + c0)) : zero4;
+      const uint4 v = *reinterpret_cast<const uint4*>(wgt + (ok ? (size_t)co * g.wtaps * g.Cs + woff : 0));
+      breg[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
     }
   };
-  auto store_tile = [&](int buf) {
-    unsigned char* As = lds + buf * (BM + BN) * ROWB;
-    unsigned char* Bs = As + BM * ROWB;
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
+    unsigned char* As = lds + buf * (BM + BN) * RB;
+    unsigned char* Bs = As + BM * RB;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) *reinterpret_cast<uint4*>(As + (r0 + 64 * i) * ROWB + cc * 16) = areg[i];
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<uint4*>(As + (r0 + RPP * i) * RB + cc * 16) = areg[i];
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int row = r0 + 64 * i;
-      if (row < BN) *reinterpret_cast<uint4*>(Bs + row * ROWB + cc * 16) = breg[i];
+      const int row = r0 + RPP * i;
+      if (row < BN) *reinterpret_cast<uint4*>(Bs + row * RB + cc * 16) = breg[i];
     }
   };
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) load_tile(kt + 1);
-    const unsigned char* As = lds + cur * (BM + BN) * ROWB;
-    const unsigned char* Bs = As + BM * ROWB;
-    frag wf[TN], xf[TM];
+  if (kt0 < kt1) {
+    load_tile(kt0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    if (kt + 1 < kt1) load_tile(kt + 1);
+    const unsigned char* As = lds + cur * (BM + BN) * RB;
+    const unsigned char* Bs = As + BM * RB;
 #pragma unroll
-    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const frag*>(Bs + (wn * WTN + i * 16 + fr) * ROWB + fq * 16);
+    for (int ks = 0; ks < KCH / 4; ++ks) {
+      frag wf[TN], xf[TM];
 #pragma unroll
-    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const frag*>(As + (wm * WTM + j * 16 + fr) * ROWB + fq * 16);
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const frag*>(Bs + (wn * WTN + i * 16 + fr) * RB + (ks * 4 + fq) * 16);
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const frag*>(As + (wm * WTM + j * 16 + fr) * RB + (ks * 4 + fq) * 16);
 #pragma unroll
-      for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
-    if (kt + 1 < KT) store_tile(cur ^ 1);
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+    }
+    if (kt + 1 < kt1) store_tile(cur ^ 1);
     __syncthreads();
   }
 
   // epilogue: lane owns pixel (col) fr of tile j and channels fq*4..fq*4+3 (rows) of tile i
   const bool accumulate = flags & 1, relu = flags & 2;
+  const bool split = gridDim.z > 1;
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int m = bm0 + wm * WTM + j * 16 + fr;
     if (m >= M) continue;
+    if (split) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int co = bn0 + wn * WTN + i * 16 + fq * 4;
+        if (co >= g.Cd) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(ws + (size_t)m * g.Cd + co + r, acc[i][j][r]);
+      }
+      continue;
+    }
     const int n = m / HWm, rem = m - n * HWm;
     const int hm = rem / g.Wm, wq = rem - hm * g.Wm;
     const size_t pix = (size_t)(n * g.Hd + hm * g.dsh + g.doh) * g.Wd + (wq * g.dsw + g.dow);
@@ -166,18 +211,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += b4[r];
       }
-      if constexpr (sizeof(T) == 4) {
-        f32x4* p = reinterpret_cast<f32x4*>(drow + co);
-        if (accumulate) { const f32x4 o = *p; for (int r = 0; r < 4; ++r) v[r] += o[r]; }
-        if (relu) for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        *p = f32x4{v[0], v[1], v[2], v[3]};
-      } else {
-        bf16x4* p = reinterpret_cast<bf16x4*>(drow + co);
-        if (accumulate) { const bf16x4 o = *p; for (int r = 0; r < 4; ++r) v[r] += (float)o[r]; }
-        if (relu) for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        *p = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-      }
+      store4<T>(drow + co, v, accumulate, relu);
     }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                            T* __restrict__ dst, const ast_gather_t g, const int M, const int flags) {
+  const int c4 = g.Cd >> 2;
+  const int HWm = g.Hm * g.Wm;
+  const size_t total = (size_t)M * c4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i / c4), co = (int)(i % c4) * 4;
+    const int n = m / HWm, rem = m - n * HWm;
+    const int hm = rem / g.Wm, wq = rem - hm * g.Wm;
+    const size_t pix = (size_t)(n * g.Hd + hm * g.dsh + g.doh) * g.Wd + (wq * g.dsw + g.dow);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ws + (size_t)m * g.Cd + co);
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if (bias) for (int r = 0; r < 4; ++r) v[r] += bias[co + r];
+    store4<T>(dst + pix * g.Cd + co, v, flags & 1, flags & 2);
   }
 }
 
@@ -213,7 +266,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dy, co
   const int ncols = g.ntaps * g.Cs;
   const int HWm = g.Hm * g.Wm;
   const int p_begin = blockIdx.z * pps, p_end = min(P, p_begin + pps);
-  if (tid < AST_MAX_TAPS) taptab[tid] = g.tap[tid];
+#pragma unroll
+  for (int t = 0; t < AST_MAX_TAPS; ++t)
+    if (tid == t) taptab[t] = g.tap[t];          // static index: a dynamic one would spill the by-value struct to scratch
   __syncthreads();
 
   // loader role: row = pixel within tile, chunk = 16-byte column chunk
@@ -226,21 +281,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dy, co
   if (xok) { const int t = xcol / g.Cs; xc0 = xcol - t * g.Cs; decode_tap(taptab[t], dh, dw_, wt); }
 
   uint4 yreg, xreg;
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-  auto load_tile = [&](int p0) {
+  auto load_tile = [&](int p0) __attribute__((always_inline)) {
     const int p = p0 + lrow;
     const bool pv = p < p_end;
-    yreg = (pv && yok) ? *reinterpret_cast<const uint4*>(dy + (size_t)p * g.Cd + ycd) : zero4;
-    xreg = zero4;
-    if (pv && xok) {
-      const int n = p / HWm, rem = p - n * HWm;
-      const int hm = rem / g.Wm, wq = rem - hm * g.Wm;
-      const int hs = hm * g.sh + g.oh + dh, ws = wq * g.sw + g.ow + dw_;
-      if ((unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws)
-        xreg = *reinterpret_cast<const uint4*>(src + ((size_t)((n * g.Hs + hs) * g.Ws + ws) * g.Cs + xc0));
-    }
+    const bool yv = pv && yok;
+    const uint4 yl = *reinterpret_cast<const uint4*>(dy + (yv ? (size_t)p * g.Cd + ycd : 0));
+    yreg = yv ? yl : make_uint4(0u, 0u, 0u, 0u);
+    const int pp = pv ? p : 0;
+    const int n = pp / HWm, rem = pp - n * HWm;
+    const int hm = rem / g.Wm, wq = rem - hm * g.Wm;
+    const int hs = hm * g.sh + g.oh + dh, ws = wq * g.sw + g.ow + dw_;
+    const bool xv = pv && xok && (unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws;
+    const uint4 xl = *reinterpret_cast<const uint4*>(src + (xv ? (size_t)((n * g.Hs + hs) * g.Ws + ws) * g.Cs + xc0 : 0));
+    xreg = xv ? xl : make_uint4(0u, 0u, 0u, 0u);
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
     *reinterpret_cast<uint4*>(&Ys[buf][lrow * PITCH + lchunk * E]) = yreg;
     *reinterpret_cast<uint4*>(&Xs[buf][lrow * PITCH + lchunk * E]) = xreg;
   };
@@ -317,12 +372,50 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dy, co
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_igemm(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t& g,
-                 int M, int flags, hipStream_t s) {
-  dim3 grid((M + BM - 1) / BM, (g.Cd + BN - 1) / BN);
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN>), grid, dim3(256), 0, s, (const T*)src, (const T*)wgt, bias,
-                     (T*)dst, g, M, flags);
+struct IgemmPlan { int bm, bn, kch, nsplit, kt_per_split; };
+
+IgemmPlan plan_igemm(const ast_gather_t& g, int M, int dtype) {
+  const int E = dtype == AST_BF16 ? 8 : 4;
+  const int nchunks = g.ntaps * (g.Cs / E);
+  IgemmPlan p;
+  const long tiles128 = (long)((M + 127) / 128) * ((g.Cd + 127) / 128);
+  if (g.Cd > 64) { if (tiles128 >= 384) { p.bm = 128; p.bn = 128; } else { p.bm = 64; p.bn = 64; } }
+  else if (g.Cd > 32) { if (M >= 128 * 512) { p.bm = 128; p.bn = 64; } else { p.bm = 64; p.bn = 64; } }
+  else if (g.Cd > 16) { p.bn = 32; p.bm = M >= 256 * 512 ? 256 : 64; }
+  else { p.bn = 16; p.bm = M >= 256 * 512 ? 256 : 64; }
+  p.kch = (p.bn >= 64 && nchunks >= 16) ? 8 : 4;
+  const int KT = (nchunks + p.kch - 1) / p.kch;
+  const long blocks = (long)((M + p.bm - 1) / p.bm) * ((g.Cd + p.bn - 1) / p.bn);
+  p.nsplit = 1;
+  if (blocks < 256 && KT >= 8) p.nsplit = (int)std::max(1L, std::min<long>(std::min<long>(KT / 4, 32), (640 + blocks - 1) / blocks));
+  p.kt_per_split = (KT + p.nsplit - 1) / p.nsplit;
+  p.nsplit = KT > 0 ? (KT + p.kt_per_split - 1) / p.kt_per_split : 1;
+  if (p.kt_per_split < 1) p.kt_per_split = 1;
+  return p;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int KCH>
+int launch_igemm(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t& g, int M, int flags,
+                 float* ws, const IgemmPlan& p, hipStream_t s) {
+  constexpr int LDS = 2 * (BM + BN) * (KCH * 16 + 16) + 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    AST_HIP(hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const int E = 16 / sizeof(T);
+  const int cpc = g.Cs / E;
+  int shift = -1;
+  if ((cpc & (cpc - 1)) == 0) { shift = 0; while ((1 << shift) < cpc) ++shift; }
+  dim3 grid((M + BM - 1) / BM, (g.Cd + BN - 1) / BN, p.nsplit);
+  if (p.nsplit > 1) AST_HIP(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)M * g.Cd, s));
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KCH>), grid, dim3(256), LDS, s, (const T*)src, (const T*)wgt, bias, (T*)dst, g, M,
+                     flags, ws, p.kt_per_split, shift);
+  if (p.nsplit > 1) {
+    const size_t total = (size_t)M * (g.Cd >> 2);
+    hipLaunchKernelGGL((splitk_finish_kernel<T>), dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, s, ws, bias,
+                       (T*)dst, g, M, flags);
+  }
   AST_CHECK_LAUNCH();
   return 0;
 }
@@ -336,35 +429,40 @@ int check_gather(const ast_gather_t* g, const char* who) {
   // destination pixels must stay inside the tensor (a fault here can reset the GPU)
   const long hmax = (long)(g->Hm - 1) * g->dsh + g->doh, wmax = (long)(g->Wm - 1) * g->dsw + g->dow;
   if (g->doh < 0 || g->dow < 0 || hmax >= g->Hd || wmax >= g->Wd) AST_FAIL("%s: destination grid exceeds tensor (%ld,%ld) vs (%d,%d)", who, hmax, wmax, g->Hd, g->Wd);
-  if ((long)g->N * g->Hs * g->Ws >= (1L << 31) / 1 || (long)g->N * g->Hm * g->Wm >= (1L << 31)) AST_FAIL("%s: pixel count overflows int32", who);
+  if ((long)g->N * g->Hs * g->Ws * g->Cs >= (1L << 31) || (long)g->N * g->Hm * g->Wm >= (1L << 31) ||
+      (long)g->Cd * g->wtaps * g->Cs >= (1L << 31)) AST_FAIL("%s: tensor exceeds 32-bit element offsets", who);
   return 0;
 }
 
 }  // namespace
 
+extern "C" long ast_igemm_ws_floats(const ast_gather_t* gp, int dtype) {
+  if (!gp || check_gather(gp, "ast_igemm_ws_floats")) return -1;
+  const int M = gp->N * gp->Hm * gp->Wm;
+  const IgemmPlan p = plan_igemm(*gp, M, dtype);
+  return p.nsplit > 1 ? (long)M * gp->Cd : 0;
+}
+
 extern "C" int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t* gp,
-                         int dtype, int flags, void* stream) {
+                         int dtype, int flags, float* ws, long ws_floats, void* stream) {
   if (int rc = check_gather(gp, "ast_igemm")) return rc;
   if (!src || !wgt || !dst) AST_FAIL("ast_igemm: null pointer");
   const ast_gather_t g = *gp;
   const int M = g.N * g.Hm * g.Wm;
   hipStream_t s = (hipStream_t)stream;
-  const long tiles128 = (long)((M + 127) / 128) * ((g.Cd + 127) / 128);
+  IgemmPlan p = plan_igemm(g, M, dtype);
+  if (p.nsplit > 1 && (!ws || ws_floats < (long)M * g.Cd)) AST_FAIL("ast_igemm: split-K needs a workspace of %ld floats (ast_igemm_ws_floats)", (long)M * g.Cd);
+#define AST_IG(BM_, BN_, WM_, WN_, K_) return launch_igemm<T, BM_, BN_, WM_, WN_, K_>(src, wgt, bias, dst, g, M, flags, ws, p, s)
   AST_DISPATCH_T(dtype, {
-    if (g.Cd > 64) {
-      if (tiles128 >= 384) return launch_igemm<T, 128, 128, 2, 2>(src, wgt, bias, dst, g, M, flags, s);
-      return launch_igemm<T, 64, 64, 2, 2>(src, wgt, bias, dst, g, M, flags, s);
-    } else if (g.Cd > 32) {
-      if (M >= 128 * 512) return launch_igemm<T, 128, 64, 2, 2>(src, wgt, bias, dst, g, M, flags, s);
-      return launch_igemm<T, 64, 64, 2, 2>(src, wgt, bias, dst, g, M, flags, s);
-    } else if (g.Cd > 16) {
-      if (M >= 256 * 512) return launch_igemm<T, 256, 32, 4, 1>(src, wgt, bias, dst, g, M, flags, s);
-      return launch_igemm<T, 64, 32, 4, 1>(src, wgt, bias, dst, g, M, flags, s);
-    } else {
-      if (M >= 256 * 512) return launch_igemm<T, 256, 16, 4, 1>(src, wgt, bias, dst, g, M, flags, s);
-      return launch_igemm<T, 64, 16, 4, 1>(src, wgt, bias, dst, g, M, flags, s);
-    }
+    if (p.bm == 128 && p.bn == 128) { if (p.kch == 8) AST_IG(128, 128, 2, 2, 8); else AST_IG(128, 128, 2, 2, 4); }
+    if (p.bm == 128 && p.bn == 64) { if (p.kch == 8) AST_IG(128, 64, 2, 2, 8); else AST_IG(128, 64, 2, 2, 4); }
+    if (p.bm == 64 && p.bn == 64) { if (p.kch == 8) AST_IG(64, 64, 2, 2, 8); else AST_IG(64, 64, 2, 2, 4); }
+    if (p.bm == 256 && p.bn == 32) AST_IG(256, 32, 4, 1, 4);
+    if (p.bm == 64 && p.bn == 32) AST_IG(64, 32, 4, 1, 4);
+    if (p.bm == 256 && p.bn == 16) AST_IG(256, 16, 4, 1, 4);
+    AST_IG(64, 16, 4, 1, 4);
   });
+#undef AST_IG
   return 0;
 }
 

@@ -56,13 +56,24 @@ typedef struct ast_gather_t {
  * nn.ConvTranspose2d fwd/bwd-data (new_decoder.py:72-96), nn.Linear fwd/bwd-data.
  * flags: bit0 accumulate into dst, bit1 ReLU. */
 int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst,
-              const ast_gather_t* g, int dtype, int flags, void* stream);
+              const ast_gather_t* g, int dtype, int flags, float* ws, long ws_floats, void* stream);
+/* f32 workspace (floats) ast_igemm needs for this geometry: >0 when the launch is split over K
+ * (under-filled grids of the deep, small-M layers), 0 otherwise, <0 on a bad geometry. */
+long ast_igemm_ws_floats(const ast_gather_t* g, int dtype);
 
 /* dw[cd][wtap[t]][c] += sum_pix dy[pix][cd] * src[gather(pix,t)][c]   (f32 atomics)
  * dy is the plain operand over the logical grid (N,Hm,Wm,Cd).
  * Replaces: weight gradients of Conv2d / ConvTranspose2d / Linear. */
 int ast_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t* g,
               int dtype, void* stream);
+
+/* Token-sized nn.Linear (M <= 64 rows, f32): y = act(x W^T + b), W row pitch ldw (W may be a row slice
+ * of in_proj_weight or the transposed pack for the data gradient).  One wave per output column. */
+int ast_skinny_gemm(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldw,
+                    int ldy, int relu, void* stream);
+/* dW[n][k] += sum_m dy[m][n] x[m][k]; db[n] += sum_m dy[m][n]  -- straight into the parameter gradients */
+int ast_linear_wgrad(const float* dy, const float* x, float* dW, float* db, int M, int N, int K, int lddy, int ldw,
+                     void* stream);
 
 /* ---- layout conversion at the module boundary ------------------------------ */
 /* x (N,C,H,W) f32, element (n,c,h,w) at n*sn + c*sc + h*sh + w  ->  NHWC dtype, Cp>=C zero padded.

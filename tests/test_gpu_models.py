@@ -141,13 +141,18 @@ def test_full_step_f32_vs_golden_and_oracle(golden_dir, name, B, S):
     assert rel_err(r["out"], o["out"]) < 1e-3
     assert math.isclose(float(r["total"]), float(o["total"]), rel_tol=1e-3)
     for tag in ("style", "content", "decoder"):
-        worst = 0.0
+        rows, num, den = [], 0.0, 0.0
         for k, p in ms[tag].named_parameters():
             ref = o["sds"][tag][k].grad
-            if ref is None or p.grad is None or float(ref.norm()) < 1e-3:
+            if ref is None or p.grad is None:
                 continue
-            worst = max(worst, rel_l2(p.grad, ref))
-        assert worst < 1e-2, (tag, worst)
+            num += float((p.grad.double().cpu() - ref.double()).pow(2).sum())
+            den += float(ref.double().pow(2).sum())
+            if float(ref.norm()) >= 1e-3:
+                rows.append((rel_l2(p.grad, ref), k, float(ref.norm())))
+        rows.sort(reverse=True)
+        assert math.sqrt(num / den) < 5e-3, (tag, math.sqrt(num / den))      # whole-model gradient
+        assert rows[0][0] < 3e-2, (tag, rows[:4])                            # worst single parameter
 
     if name == "b2s2":   # eval-mode autoregressive decode (config 4 plumbing), after the one training step
         gi = np.load(os.path.join(golden_dir, "infer_b2s2.npz"))

@@ -15,12 +15,12 @@ recs = []
 orig_ig, orig_wg = ops._igemm, ops._wgrad
 def ig(src, wgt, bias, dst, g, flags=0):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); ops.check(ops.lib().ast_igemm(ops.ptr(src), ops.ptr(wgt), ops.ptr(bias), ops.ptr(dst), g, ops.dcode(src.dtype), flags, ops.stream())); e1.record()
+    e0.record(); orig_ig(src, wgt, bias, dst, g, flags); e1.record()
     M = g.N*g.Hm*g.Wm
     recs.append(("igemm " + ops._igemm_config(g, M) + (" f32" if src.dtype == torch.float32 else ""), M, g.Cd, g.ntaps*g.Cs, g.ntaps, ops._gemm_cost(g, src.element_size()), e0, e1))
 def wg(dy, src, dwp, g):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); ops.check(ops.lib().ast_wgrad(ops.ptr(dy), ops.ptr(src), ops.ptr(dwp), g, ops.dcode(src.dtype), ops.stream())); e1.record()
+    e0.record(); orig_wg(dy, src, dwp, g); e1.record()
     M = g.N*g.Hm*g.Wm
     recs.append(("wgrad" + (" f32" if src.dtype == torch.float32 else ""), M, g.Cd, g.ntaps*g.Cs, g.ntaps, ops._gemm_cost(g, src.element_size(), True), e0, e1))
 ops._igemm, ops._wgrad = ig, wg
