@@ -29,7 +29,8 @@ class Gather(C.Structure):
 class WeightDesc(C.Structure):
     """ast_weight_desc_t"""
     _fields_ = [("w", vp), ("u", vp), ("v", vp), ("sigma", vp), ("scratch", vp), ("wf", vp), ("wb", vp)] + \
-               [(n, i32) for n in ("Co", "Ci", "KK", "s_co", "s_ci", "Cop", "Cip", "power_iter")]
+               [(n, i32) for n in ("Co", "Ci", "KK", "s_co", "s_ci", "Cop", "Cip", "power_iter")] + \
+               [("dwp", vp), ("grad", vp), ("inner", vp), ("dwp_from_wb", i32), ("pad_", i32)]
 
 
 _SIGS = {
@@ -43,6 +44,8 @@ _SIGS = {
     "ast_nhwc_to_nchw": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "ast_cast": ([vp, i32, vp, i32, i64, vp], i32),
     "ast_weights_prepare_v": ([vp, vp, i32, i32, i32, C.c_long, vp], i32),
+    "ast_weight_grads_flush_v": ([vp, i32, C.c_long, vp], i32),
+    "ast_dropout_fwd": ([vp, vp, vp, i64, f32, C.c_uint64, vp, vp], i32),
     "ast_weight_grad_unpack": ([vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp], i32),
     "ast_chan_stats": ([vp, vp, i32, i32, i32, i32, vp], i32),
     "ast_norm_finalize": ([vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp, vp, vp, vp], i32),

@@ -28,6 +28,9 @@ class WeightBank:
         self.specs = []
         self.entries: list[PackedWeight] = []
         self._key = None
+        self._keys = {}
+        self._flush_pending = False
+        self.d_train = self.d_eval = None
         self.hold = False     # True: packed images are current (several forwards between optimiser steps)
 
     def add(self, weight, kind, dtype_fn, u=None, v=None, bias=None, rows=None):
@@ -37,14 +40,28 @@ class WeightBank:
         self.entries.append(PackedWeight())
         return self.entries[-1]
 
-    def _signature(self):
-        return tuple((w.data_ptr(), w.device, fn()) for w, _, fn, *_ in self.specs)
+    def _signature(self, training):
+        return (training,) + tuple((w.data_ptr(), w.device, fn(), (None if w.grad is None else w.grad.data_ptr()) if training else 0)
+                                   for w, _, fn, *_ in self.specs)
 
-    def _build(self):
+    def _build(self, training):
         dev = self.specs[0][0].device
-        descs_t, descs_e, dts = [], [], []
+        first = self._key is None or self._key[1:] != self._signature(training)[1:] or True
+        descs, dts = [], []
         self.max_co = self.max_cols = self.max_packed = 1
-        for e, (w, kind, dtype_fn, u, v, bias, rows) in zip(self.entries, self.specs):
+        # packed f32 gradient staging for every conv / conv-transpose weight: ONE arena, zeroed by the
+        # pack kernel of each training forward, unpacked by ONE batched launch pair after backward
+        sizes = []
+        for (w, kind, *_rest) in self.specs:
+            if kind == "linear":
+                sizes.append(0)
+            else:
+                co, ci = (w.shape[0], w.shape[1]) if kind == "conv" else (w.shape[1], w.shape[0])
+                sizes.append(pad8(co) * w.shape[2] * w.shape[3] * pad8(ci))
+        if training and (getattr(self, "dw_arena", None) is None or self.dw_arena.device != dev):
+            self.dw_arena = torch.zeros(max(1, sum(sizes)), dtype=torch.float32, device=dev)
+        off = 0
+        for e, (w, kind, dtype_fn, u, v, bias, rows), sz in zip(self.entries, self.specs, sizes):
             dt = dtype_fn()
             if kind == "conv":
                 Co, Ci, k, _ = w.shape
@@ -56,42 +73,60 @@ class WeightBank:
                 Co, Ci = w.shape
                 r0, r1 = rows if rows else (0, Co)
                 Co, KK, s_co, s_ci, w_off, b_off = r1 - r0, 1, Ci, 1, r0 * Ci, r0
-            e.weight, e.u, e.v, e.bias = w, u, v, bias
+            n = pad8(Co) * KK * pad8(Ci)
+            if e.wf is None or e.wf.device != dev or e.wf.dtype != dt or e.wf.numel() != n:
+                e.wf = torch.empty(n, dtype=dt, device=dev)
+                e.wb = torch.empty(n, dtype=dt, device=dev)
+                e.sigma = torch.ones(1, dtype=torch.float32, device=dev)
+                e.scratch = torch.zeros(Co + Ci * KK, dtype=torch.float32, device=dev)
+                e.gtmp = torch.zeros(1, dtype=torch.float32, device=dev)
+                e.bias_pad = torch.zeros(pad8(Co), dtype=torch.float32, device=dev) if (bias is not None and Co != pad8(Co)) else None
+            e.weight, e.u, e.v, e.bias, e.bank = w, u, v, bias, self
             e.Co, e.Ci, e.KK, e.s_co, e.s_ci, e.w_off, e.b_off = Co, Ci, KK, s_co, s_ci, w_off, b_off
             e.Cop, e.Cip, e.dtype = pad8(Co), pad8(Ci), dt
-            n = e.Cop * KK * e.Cip
-            e.wf = torch.empty(n, dtype=dt, device=dev)
-            e.wb = torch.empty(n, dtype=dt, device=dev)
-            e.sigma = torch.ones(1, dtype=torch.float32, device=dev)
-            e.scratch = torch.zeros(Co + Ci * KK, dtype=torch.float32, device=dev)
-            e.gtmp = torch.zeros(1, dtype=torch.float32, device=dev)
-            e.bias_pad = torch.zeros(e.Cop, dtype=torch.float32, device=dev) if (bias is not None and Co != e.Cop) else None
-            for power, lst in ((1, descs_t), (0, descs_e)):
-                lst.append(WeightDesc(w=w.data_ptr() + 4 * w_off, u=ptr(u), v=ptr(v), sigma=ptr(e.sigma),
-                                      scratch=ptr(e.scratch), wf=ptr(e.wf), wb=ptr(e.wb), Co=Co, Ci=Ci, KK=KK, s_co=s_co,
-                                      s_ci=s_ci, Cop=e.Cop, Cip=e.Cip, power_iter=power))
+            e.dwp = None
+            grad_ptr = None
+            if training and sz:
+                e.dwp = self.dw_arena[off:off + sz]
+                off += sz
+                grad_ptr = ops.acc_grad(w).data_ptr() + 4 * w_off
+            descs.append(WeightDesc(w=w.data_ptr() + 4 * w_off, u=ptr(u), v=ptr(v), sigma=ptr(e.sigma), scratch=ptr(e.scratch),
+                                    wf=ptr(e.wf), wb=ptr(e.wb), Co=Co, Ci=Ci, KK=KK, s_co=s_co, s_ci=s_ci, Cop=e.Cop, Cip=e.Cip,
+                                    power_iter=1 if training else 0, dwp=ptr(e.dwp), grad=grad_ptr, inner=ptr(e.gtmp),
+                                    dwp_from_wb=1 if kind == "convT" else 0, pad_=0))
             dts.append(dcode(dt))
             self.max_co = max(self.max_co, Co)
             self.max_cols = max(self.max_cols, Ci * KK)
             self.max_packed = max(self.max_packed, n)
-
-        def to_dev(lst):
-            arr = (WeightDesc * len(lst))(*lst)
-            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            return host.to(dev)
-
-        self.d_train, self.d_eval = to_dev(descs_t), to_dev(descs_e)
+        arr = (WeightDesc * len(descs))(*descs)
+        dev_descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        if training:
+            self.d_train = dev_descs
+        else:
+            self.d_eval = dev_descs
         self.d_dtypes = torch.tensor(dts, dtype=torch.int32, device=dev)
-        self._key = self._signature()
+        self._keys[training] = self._signature(training)
 
     def prepare(self, training: bool):
         if self.hold:
             return
-        if self._key != self._signature():
-            self._build()
+        training = bool(training) and torch.is_grad_enabled()
+        if self._keys.get(training) != self._signature(training):
+            self._build(training)
         d = self.d_train if training else self.d_eval
         check(lib().ast_weights_prepare_v(ptr(d), ptr(self.d_dtypes), len(self.entries), self.max_co, self.max_cols,
                                           self.max_packed, stream()), "ast_weights_prepare_v")
+
+    # ---- batched weight-gradient unpack, once per backward pass ----------------------
+    def request_flush(self):
+        if not self._flush_pending:
+            self._flush_pending = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._flush)
+
+    def _flush(self):
+        self._flush_pending = False
+        check(lib().ast_weight_grads_flush_v(ptr(self.d_train), len(self.entries), self.max_packed, stream()),
+              "ast_weight_grads_flush_v")
 
 
 def img_dtype():

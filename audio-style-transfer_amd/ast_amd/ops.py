@@ -146,7 +146,10 @@ class PackedWeight:
     """One GEMM weight of a model: the f32 master parameter (PyTorch layout),
     optional spectral-norm buffers and its two packed images (see WeightBank)."""
     __slots__ = ("weight", "u", "v", "bias", "Co", "Ci", "KK", "s_co", "s_ci", "Cop", "Cip", "dtype", "wf", "wb",
-                 "sigma", "scratch", "bias_pad", "w_off", "b_off", "transposed", "gtmp")
+                 "sigma", "scratch", "bias_pad", "w_off", "b_off", "transposed", "gtmp", "dwp", "bank")
+
+    def __init__(self):
+        self.wf = self.wb = self.dwp = self.bank = None
 
     def bias_ptr_tensor(self):
         if self.bias is None:
@@ -195,9 +198,10 @@ class Conv2dFn(torch.autograd.Function):
         pw, (k, stride, pad) = ctx.pw, ctx.args
         dy = dy.contiguous()
         N, H, W, Cs = x.shape
-        dwp = torch.zeros((pw.Cop, pw.KK, pw.Cip), dtype=torch.float32, device=x.device)
-        _wgrad(dy, x, dwp, ctx.geom)
-        pw.add_weight_grad(dwp, 0)
+        if pw.dwp is None:
+            raise RuntimeError("weights were prepared in eval/no-grad mode; run the forward in training mode before backward")
+        _wgrad(dy, x, pw.dwp, ctx.geom)           # into the per-model staging arena; unpacked once after backward
+        pw.bank.request_flush()
         if ctx.bias_grad:
             pw.add_bias_grad(dy)
         dx = None
@@ -233,9 +237,10 @@ class ConvT2dFn(torch.autograd.Function):
         # x pixel (h,w) meets dy pixel (h*s - p + kh, ...): the direct geometry with dy as source
         g, (Hx, Wx) = gather_direct(N, Ho, Wo, pw.Cop, Cs, k, stride, pad)
         assert (Hx, Wx) == (H, W), "ConvTranspose2d geometry mismatch"
-        dwp = torch.zeros((pw.Cip, pw.KK, pw.Cop), dtype=torch.float32, device=x.device)
-        _wgrad(x, dy, dwp, g)
-        pw.add_weight_grad(dwp, 1)
+        if pw.dwp is None:
+            raise RuntimeError("weights were prepared in eval/no-grad mode; run the forward in training mode before backward")
+        _wgrad(x, dy, pw.dwp, g)
+        pw.bank.request_flush()
         if ctx.bias_grad:
             pw.add_bias_grad(dy)
         dx = None
@@ -601,10 +606,36 @@ class MulMaskFn(torch.autograd.Function):
         return dx, None
 
 
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout on f32 token tensors: mask generation and application in one launch."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        x = x.contiguous()
+        if _DropState.counter is None or _DropState.counter.device != x.device:
+            _DropState.counter = torch.zeros(1, dtype=torch.int64, device=x.device)
+        _DropState.calls += 1
+        y, mask = torch.empty_like(x), torch.empty_like(x)
+        check(lib().ast_dropout_fwd(ptr(x), ptr(y), ptr(mask), x.numel(), p, _DropState.seed + 7919 * _DropState.calls,
+                                    ptr(_DropState.counter), stream()), "ast_dropout_fwd")
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib().ast_mul(ptr(dy), ptr(mask), ptr(dx), dy.numel(), dcode(dy.dtype), stream()), "ast_mul")
+        return dx, None
+
+
 def dropout(x, p, training):
     if not training or p <= 0.0:
         return x
-    return MulMaskFn.apply(x, dropout_mask(x.shape, p, x.device))
+    if x.dtype != torch.float32:
+        return MulMaskFn.apply(x, dropout_mask(x.shape, p, x.device))
+    return DropoutFn.apply(x, float(p))
 
 
 # ---------------------------------------------------------------------------

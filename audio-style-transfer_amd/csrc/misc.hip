@@ -273,7 +273,29 @@ __global__ void dropout_mask_kernel(float* __restrict__ mask, size_t n, float p,
   }
 }
 
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ mask, size_t n, float p,
+                                   uint64_t seed, const int64_t* __restrict__ d_offset) {
+  const uint64_t base = mix64(seed ^ mix64((uint64_t)(d_offset ? *d_offset : 0)));
+  const float keep = 1.f / (1.f - p);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t r = (uint32_t)(mix64(base + i) >> 40);
+    const float m = ((float)r * (1.f / 16777216.f)) >= p ? keep : 0.f;
+    mask[i] = m;
+    y[i] = x[i] * m;
+  }
+}
+
 }  // namespace
+
+extern "C" int ast_dropout_fwd(const float* x, float* y, float* mask, int64_t n, float p, uint64_t seed, const int64_t* d_offset,
+                               void* stream) {
+  if (!x || !y || !mask || n < 0 || p < 0.f || p >= 1.f) AST_FAIL("ast_dropout_fwd: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, x, y, mask, (size_t)n, p, seed,
+                     d_offset);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int ast_nchw_to_nhwc(const float* x, void* y, int N, int C, int H, int W, int64_t sn, int64_t sc, int64_t sh, int Cp,
                                 int dtype, void* stream) {

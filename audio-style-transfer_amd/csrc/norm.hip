@@ -73,12 +73,13 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const T* __restrict__ 
   }
 }
 
-__global__ void norm_finalize_kernel(const float* __restrict__ sums, int N, int HW, int C, int Creal, int instance,
+// one wave per output statistic (channel for batch norm, (n,c) for instance norm); lanes stride over images
+__global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ sums, int N, int HW, int C, int Creal, int instance,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float* running_mean, float* running_var, int eval_mode, float eps,
                                      float* __restrict__ mean, float* __restrict__ rstd,
                                      float* __restrict__ scale, float* __restrict__ shift) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int total = instance ? N * C : C;
   if (idx >= total) return;
   const int c = idx % C;
@@ -91,17 +92,19 @@ __global__ void norm_finalize_kernel(const float* __restrict__ sums, int N, int 
     m = c < Creal ? running_mean[c] : 0.f;
     var = c < Creal ? running_var[c] : 1.f;
   } else {
-    double s0 = 0.0, s1 = 0.0;
-    for (int n = 0; n < N; ++n) { s0 += sums[((size_t)n * C + c) * 2]; s1 += sums[((size_t)n * C + c) * 2 + 1]; }
+    float s0 = 0.f, s1 = 0.f;
+    for (int n = lane; n < N; n += 64) { s0 += sums[((size_t)n * C + c) * 2]; s1 += sums[((size_t)n * C + c) * 2 + 1]; }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
     const double cnt = (double)N * HW;
-    const double md = s0 / cnt;
-    const double vd = fmax(s1 / cnt - md * md, 0.0);
+    const double md = (double)s0 / cnt;
+    const double vd = fmax((double)s1 / cnt - md * md, 0.0);
     m = (float)md; var = (float)vd;
-    if (running_mean && c < Creal) {
+    if (lane == 0 && running_mean && c < Creal) {
       running_mean[c] = 0.9f * running_mean[c] + 0.1f * m;
       running_var[c] = 0.9f * running_var[c] + 0.1f * (float)(vd * cnt / fmax(cnt - 1.0, 1.0));
     }
   }
+  if (lane != 0) return;
   const float r = rsqrtf(var + eps);
   mean[idx] = m; rstd[idx] = r;
   const float gmm = c < Creal ? gamma[c] : 0.f, bt = c < Creal ? beta[c] : 0.f;
@@ -142,17 +145,35 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
   }
 }
 
-// k1[c][3] for the batch branch, k2[n][c][3] for the instance branch
-__global__ void norm_bwd_finalize_kernel(const float* __restrict__ sums3, int N, int HW, int C, int Creal,
+// k1[c][3] for the batch branch, k2[n][c][3] for the instance branch; one wave per channel, lanes over images
+__global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __restrict__ sums3, int N, int HW, int C, int Creal,
                                          const float* gamma1, const float* mean1, const float* rstd1,
                                          float* dgamma1, float* dbeta1, float* k1,
                                          const float* gamma2, const float* mean2, const float* rstd2,
                                          float* dgamma2, float* dbeta2, float* k2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   const bool real = c < Creal;
-  double S0 = 0.0, S1 = 0.0;
-  for (int n = 0; n < N; ++n) { S0 += sums3[((size_t)n * C + c) * 3]; S1 += sums3[((size_t)n * C + c) * 3 + 1]; }
+  float s0 = 0.f, s1 = 0.f, dg = 0.f;
+  for (int n = lane; n < N; n += 64) {
+    const size_t i = (size_t)n * C + c;
+    const float T0 = sums3[i * 3], T1 = sums3[i * 3 + 1];
+    s0 += T0; s1 += T1;
+    if (k2) {
+      if (real) {
+        const double T2 = sums3[i * 3 + 2];
+        const double P = (double)HW, g = gamma2[c], m = mean2[i], r = rstd2[i];
+        const double Q = r * (T2 - m * (double)T0);
+        dg += (float)Q;
+        k2[i * 3 + 0] = (float)(g * r);
+        k2[i * 3 + 1] = (float)(-g * r * r * Q / P);
+        k2[i * 3 + 2] = (float)(-g * r * (double)T0 / P + g * r * r * m * Q / P);
+      } else { k2[i * 3] = k2[i * 3 + 1] = k2[i * 3 + 2] = 0.f; }
+    }
+  }
+  const double S0 = wave_sum(s0), S1 = wave_sum(s1);
+  dg = wave_sum(dg);
+  if (lane != 0) return;
   if (k1) {
     if (real) {
       const double P = (double)N * HW, g = gamma1[c], m = mean1[c], r = rstd1[c];
@@ -164,22 +185,7 @@ __global__ void norm_bwd_finalize_kernel(const float* __restrict__ sums3, int N,
       k1[c * 3 + 2] = (float)(-g * r * S0 / P + g * r * r * m * Q / P);
     } else { k1[c * 3] = k1[c * 3 + 1] = k1[c * 3 + 2] = 0.f; }
   }
-  if (k2) {
-    double dg = 0.0;
-    for (int n = 0; n < N; ++n) {
-      const size_t i = (size_t)n * C + c;
-      if (real) {
-        const double T0 = sums3[i * 3], T2 = sums3[i * 3 + 2];
-        const double P = (double)HW, g = gamma2[c], m = mean2[i], r = rstd2[i];
-        const double Q = r * (T2 - m * T0);
-        dg += Q;
-        k2[i * 3 + 0] = (float)(g * r);
-        k2[i * 3 + 1] = (float)(-g * r * r * Q / P);
-        k2[i * 3 + 2] = (float)(-g * r * T0 / P + g * r * r * m * Q / P);
-      } else { k2[i * 3] = k2[i * 3 + 1] = k2[i * 3 + 2] = 0.f; }
-    }
-    if (real) { if (dgamma2) dgamma2[c] += (float)dg; if (dbeta2) dbeta2[c] += (float)S0; }
-  }
+  if (k2 && real) { if (dgamma2) dgamma2[c] += dg; if (dbeta2) dbeta2[c] += (float)S0; }
 }
 
 template <typename T>
@@ -290,7 +296,7 @@ extern "C" int ast_norm_finalize(const float* sums, int N, int HW, int C, int Cr
   if (!eval_mode && !sums) AST_FAIL("ast_norm_finalize: sums required in training mode");
   if (eval_mode && (instance || !running_mean || !running_var)) AST_FAIL("ast_norm_finalize: eval mode needs running stats");
   const int total = instance ? N * C : C;
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, N, HW, C,
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums, N, HW, C,
                      Creal, instance, gamma, beta, running_mean, running_var, eval_mode, eps, mean, rstd, scale, shift);
   AST_CHECK_LAUNCH();
   return 0;
@@ -329,7 +335,7 @@ extern "C" int ast_norm_bwd_finalize(const float* sums3, int N, int HW, int C, i
                                      const float* gamma2, const float* mean2, const float* rstd2, float* dgamma2,
                                      float* dbeta2, float* k2, void* stream) {
   if (!sums3 || (k1 && (!gamma1 || !mean1 || !rstd1)) || (k2 && (!gamma2 || !mean2 || !rstd2))) AST_FAIL("ast_norm_bwd_finalize: bad args");
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums3, N, HW, C, Creal,
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums3, N, HW, C, Creal,
                      gamma1, mean1, rstd1, dgamma1, dbeta1, k1, gamma2, mean2, rstd2, dgamma2, dbeta2, k2);
   AST_CHECK_LAUNCH();
   return 0;

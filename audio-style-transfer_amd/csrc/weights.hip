@@ -13,16 +13,22 @@ __device__ __forceinline__ size_t woff(const ast_weight_desc_t& d, int co, int c
 }
 
 // t[j] = sum_co W(co, j) u[co],  j = ci*KK + tap  -> scratch[Co + j]
+// rows are split over grid.z (RZ chunks) and summed with atomics; scratch[Co..] is zeroed by sn_pack_kernel
+// of the previous forward (and at allocation), so the launch needs no memset.
+constexpr int RZ = 8;
 __global__ __launch_bounds__(256) void sn_wt_u_kernel(const ast_weight_desc_t* __restrict__ descs) {
   const ast_weight_desc_t d = descs[blockIdx.y];
   if (!d.u || !d.power_iter) return;
   const int ncols = d.Ci * d.KK;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= ncols) return;
+  const int rows_per = (d.Co + RZ - 1) / RZ;
+  const int c0 = blockIdx.z * rows_per, c1 = min(d.Co, c0 + rows_per);
+  if (c0 >= c1) return;
   const int ci = j / d.KK, tap = j - ci * d.KK;
   float acc = 0.f;
-  for (int co = 0; co < d.Co; ++co) acc += d.w[woff(d, co, ci, tap)] * d.u[co];
-  d.scratch[d.Co + j] = acc;
+  for (int co = c0; co < c1; ++co) acc += d.w[woff(d, co, ci, tap)] * d.u[co];
+  unsafeAtomicAdd(d.scratch + d.Co + j, acc);
 }
 
 // v = t/|t| (training) ; s[co] = sum_j W(co,j) v[j] -> scratch[co]; one wave per row
@@ -102,7 +108,50 @@ __global__ __launch_bounds__(256) void sn_pack_kernel(const ast_weight_desc_t* _
     if (blockIdx.x == 0 && threadIdx.x == 0) d.sigma[0] = sigma;
     inv_sigma = 1.f / sigma;
   }
+  __syncthreads();
+  if (d.u && blockIdx.x == 0)                       // leave t = W^T u zeroed for the next forward's atomics
+    for (int j = threadIdx.x; j < d.Ci * d.KK; j += 256) d.scratch[d.Co + j] = 0.f;
   if (dtypes[blockIdx.y] == AST_BF16) pack_body<bf16_t>(d, inv_sigma); else pack_body<float>(d, inv_sigma);
+  if (d.dwp && d.power_iter) {                      // training forward: fresh gradient staging for this step
+    const size_t nf = (size_t)d.Cop * d.KK * d.Cip;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nf; i += (size_t)gridDim.x * 256) d.dwp[i] = 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && d.inner) d.inner[0] = 0.f;
+  }
+}
+
+// batched backward: inner[w] = <dWp, W>/sigma for spectral-normalised weights
+__global__ __launch_bounds__(256) void flush_inner_kernel(const ast_weight_desc_t* __restrict__ descs) {
+  __shared__ float red[17];
+  const ast_weight_desc_t d = descs[blockIdx.y];
+  if (!d.dwp || !d.u) return;
+  const size_t n = (size_t)d.Co * d.Ci * d.KK;
+  float q = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int tap = (int)(i % d.KK);
+    const size_t t = i / d.KK;
+    const int ci = (int)(t % d.Ci), co = (int)(t / d.Ci);
+    const size_t pi = d.dwp_from_wb ? ((size_t)ci * d.KK + tap) * d.Cop + co : ((size_t)co * d.KK + tap) * d.Cip + ci;
+    q += d.dwp[pi] * d.w[woff(d, co, ci, tap)];
+  }
+  q = block_sum(q, red);
+  if (threadIdx.x == 0 && q != 0.f) unsafeAtomicAdd(d.inner, q / d.sigma[0]);
+}
+
+__global__ __launch_bounds__(256) void flush_unpack_kernel(const ast_weight_desc_t* __restrict__ descs) {
+  const ast_weight_desc_t d = descs[blockIdx.y];
+  if (!d.dwp || !d.grad) return;
+  const size_t n = (size_t)d.Co * d.Ci * d.KK;
+  const float inner = d.u ? d.inner[0] : 0.f;
+  const float inv_sigma = d.u ? 1.f / d.sigma[0] : 1.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int tap = (int)(i % d.KK);
+    const size_t t = i / d.KK;
+    const int ci = (int)(t % d.Ci), co = (int)(t / d.Ci);
+    const size_t pi = d.dwp_from_wb ? ((size_t)ci * d.KK + tap) * d.Cop + co : ((size_t)co * d.KK + tap) * d.Cip + ci;
+    float gv = d.dwp[pi];
+    if (d.u) gv = (gv - inner * d.u[co] * d.v[ci * d.KK + tap]) * inv_sigma;
+    d.grad[woff(d, co, ci, tap)] += gv;
+  }
 }
 
 // ---- backward --------------------------------------------------------------------
@@ -149,10 +198,20 @@ extern "C" int ast_weights_prepare_v(const ast_weight_desc_t* descs, const int* 
                                      long max_packed, void* stream) {
   if (!descs || !dtypes || n <= 0 || max_co <= 0 || max_cols <= 0) AST_FAIL("ast_weights_prepare: bad args");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(sn_wt_u_kernel, dim3((max_cols + 255) / 256, n), dim3(256), 0, s, descs);
+  hipLaunchKernelGGL(sn_wt_u_kernel, dim3((max_cols + 255) / 256, n, RZ), dim3(256), 0, s, descs);
   hipLaunchKernelGGL(sn_w_v_kernel, dim3((max_co + 3) / 4, n), dim3(256), 0, s, descs);
   const int nb = (int)std::max(1L, std::min(64L, (max_packed + 2047) / 2048));
   hipLaunchKernelGGL(sn_pack_kernel, dim3(nb, n), dim3(256), 0, s, descs, dtypes);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_weight_grads_flush_v(const ast_weight_desc_t* descs, int n, long max_elems, void* stream) {
+  if (!descs || n <= 0) AST_FAIL("ast_weight_grads_flush_v: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = (int)std::max(1L, std::min(64L, (max_elems + 4095) / 4096));
+  hipLaunchKernelGGL(flush_inner_kernel, dim3(nb, n), dim3(256), 0, s, descs);
+  hipLaunchKernelGGL(flush_unpack_kernel, dim3(nb, n), dim3(256), 0, s, descs);
   AST_CHECK_LAUNCH();
   return 0;
 }

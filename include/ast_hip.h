@@ -95,6 +95,11 @@ typedef struct ast_weight_desc_t {
   void* wb;             /* packed [Cip][KK][Cop]  (rows = in channel) or NULL */
   int32_t Co, Ci, KK, s_co, s_ci, Cop, Cip;
   int32_t power_iter;   /* 1 in training, 0 in eval */
+  float* dwp;           /* packed f32 gradient staging (zeroed by ast_weights_prepare_v in training) or NULL */
+  float* grad;          /* gradient of `w` (same layout as w), accumulated by ast_weight_grads_flush_v */
+  float* inner;         /* [1] scratch: <dWp, W/sigma> */
+  int32_t dwp_from_wb;  /* 0: dwp is [Cop][KK][Cip]; 1: [Cip][KK][Cop] */
+  int32_t pad_;
 } ast_weight_desc_t;
 /* descs: DEVICE array of n descriptors, dtypes: DEVICE int[n] (packed dtype per weight).
  * Runs the power iteration (if requested), sigma = u^T W v, and writes W/sigma in both
@@ -102,6 +107,9 @@ typedef struct ast_weight_desc_t {
  * the maxima over the descriptors of Co, Ci*KK and Cop*KK*Cip (grid sizing). */
 int ast_weights_prepare_v(const ast_weight_desc_t* descs, const int* dtypes, int n, int max_co, int max_cols,
                           long max_packed, void* stream);
+/* Batched form of ast_weight_grad_unpack for every descriptor with dwp != NULL: two launches per model
+ * (inner products, then grad += (dWp - <dWp,W/sigma> u v^T)/sigma), run once at the end of backward. */
+int ast_weight_grads_flush_v(const ast_weight_desc_t* descs, int n, long max_elems, void* stream);
 /* g_orig += (dWp - <dWp,W/sigma> u v^T)/sigma, dWp packed [Cop][KK][Cip] (from_wb=0)
  * or [Cip][KK][Cop] (from_wb=1).  u NULL => plain unpack-accumulate. */
 int ast_weight_grad_unpack(const float* dwp, int from_wb, const float* w, const float* u, const float* v,
@@ -166,6 +174,8 @@ int ast_attn_bwd(const float* dout, const float* q, const float* k, const float*
 int ast_colsum_acc(const void* x, int64_t rows, int C, int Creal, float* out, int dtype, void* stream);
 int ast_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream);
 int ast_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
+/* fused counter-based dropout: mask[i] in {0, 1/(1-p)} is generated, stored (for backward) and applied: y = x*mask */
+int ast_dropout_fwd(const float* x, float* y, float* mask, int64_t n, float p, uint64_t seed, const int64_t* d_offset, void* stream);
 /* counter-based dropout: mask[i] in {0, 1/(1-p)} (f32), y = x*mask */
 int ast_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, const int64_t* d_offset, void* stream);
 int ast_mul(const void* a, const float* mask, void* y, int64_t n, int dtype, void* stream);
