@@ -1,43 +1,57 @@
 // Token-sized GEMMs (M <= 64 rows: transformer / projection / discriminator
 // linears at B*(S+1) <= 40 rows).  An MFMA tile would be >75 % padding and the
-// launch is latency-bound, so these run as wave-per-output-column dot products:
-// the weight row streams once (coalesced 16-B loads), the <=64 activation rows
-// come from L1/L2.  The weight gradient + bias gradient are one launch that adds
+// launch is latency-bound, so one workgroup computes one 16x16 f32 MFMA tile with its
+// four waves splitting K (LDS reduce): short dependency chains, every weight byte read
+// once.  The weight gradient + bias gradient are one launch that adds
 // straight into the parameter gradient (no packed staging: plain linears have no
 // spectral norm).
 #include "ast_common.h"
 #include "../../include/ast_hip.h"
 
 namespace {
-constexpr int RG = 8;   // activation rows per register group
 
-// y[m][n] = act(sum_k x[m][k] * w[n][k] + b[n]);  w row pitch = ldw.  One wave per column n.
+// y[m][n] = act(sum_k x[m][k] * w[n][k] + b[n]).  One workgroup = one 16(n) x 16(m) output tile; its 4 waves
+// split K and are reduced through LDS.  v_mfma_f32_16x16x4_f32 (exact f32): the weight tile is the A operand
+// so each lane ends up with 4 consecutive n of one token row m -> one 16-byte store.  Lane (i = l&15, g = l>>4)
+// loads 16 B of row i at k = kb + 16 s + 4 g: the four MFMAs of a step contract k = 4 g + e over g (e = 0..3),
+// the same k permutation on both operands.
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int M, int N,
-                                                           int K, int ldw, int ldy, int relu) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  const float* wr = w + (size_t)n * ldw;
-  const float bn = bias ? bias[n] : 0.f;
-  for (int m0 = 0; m0 < M; m0 += RG) {
-    float acc[RG];
+                                                           int K, int ldx, int ldw, int ldy, int relu) {
+  __shared__ f32x4 part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int kslice = ((K + 63) / 64) * 16;            // k per wave, multiple of 16
+  const int kb = wave * kslice;
+  const bool nv = n0 + i < N, mv = m0 + i < M;
+  const float* wr = w + (size_t)(nv ? n0 + i : 0) * ldw;
+  const float* xr = x + (size_t)(mv ? m0 + i : 0) * ldx;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int s = 0; s < kslice; s += 16) {
+    const int k = kb + s + 4 * g;
+    const bool kv = k < K;
+    const f32x4 wl = *reinterpret_cast<const f32x4*>(wr + (kv ? k : 0));
+    const f32x4 xl = *reinterpret_cast<const f32x4*>(xr + (kv ? k : 0));
+    const bool wok = kv && nv, xok = kv && mv;
 #pragma unroll
-    for (int r = 0; r < RG; ++r) acc[r] = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wok ? wl[e] : 0.f, xok ? xl[e] : 0.f, acc, 0, 0, 0);
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave != 0) return;
+  f32x4 r = part[0][lane];
 #pragma unroll
-      for (int r = 0; r < RG; ++r) {
-        if (m0 + r < M) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)(m0 + r) * K + k);
-          acc[r] += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
-        }
-      }
-    }
+  for (int q = 1; q < 4; ++q) { const f32x4 t = part[q][lane]; r[0] += t[0]; r[1] += t[1]; r[2] += t[2]; r[3] += t[3]; }
+  const int m = m0 + i, nb = n0 + 4 * g;              // D[row = 4 g + r (n)][col = i (m)]
+  if (m >= M) return;
 #pragma unroll
-    for (int r = 0; r < RG; ++r) {
-      const float s = wave_sum(acc[r]) + bn;
-      if (lane == 0 && m0 + r < M) y[(size_t)(m0 + r) * ldy + n] = relu ? fmaxf(s, 0.f) : s;
+  for (int q = 0; q < 4; ++q) {
+    const int n = nb + q;
+    if (n < N) {
+      float v = r[q] + (bias ? bias[n] : 0.f);
+      y[(size_t)m * ldy + n] = relu ? fmaxf(v, 0.f) : v;
     }
   }
 }
@@ -63,7 +77,8 @@ extern "C" int ast_skinny_gemm(const float* x, const float* w, const float* bias
                                int relu, void* stream) {
   if (!x || !w || !y || M < 1 || M > 64 || N < 1 || K < 4 || (K & 3) || (ldw & 3)) AST_FAIL("ast_skinny_gemm: bad args M=%d N=%d K=%d", M, N, K);
   if ((((uintptr_t)x) | ((uintptr_t)w)) & 15) AST_FAIL("ast_skinny_gemm: operands must be 16-byte aligned");
-  hipLaunchKernelGGL(skinny_gemm_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, M, N, K, ldw, ldy, relu);
+  hipLaunchKernelGGL(skinny_gemm_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, M, N, K, K,
+                     ldw, ldy, relu);
   AST_CHECK_LAUNCH();
   return 0;
 }
