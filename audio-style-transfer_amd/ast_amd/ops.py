@@ -115,8 +115,9 @@ def _igemm(src, wgt, bias, dst, g, flags=0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     need = _ws_need(g, dcode(src.dtype))
-    ws = torch.empty(need, dtype=torch.float32, device=src.device) if need > 0 else None
-    check(lib().ast_igemm(ptr(src), ptr(wgt), ptr(bias), ptr(dst), g, dcode(src.dtype), flags, ptr(ws), need, stream()), "ast_igemm")
+    ws = _clean_scratch(need, src.device) if need > 0 else None        # persistent, handed back zeroed by the finish pass
+    check(lib().ast_igemm(ptr(src), ptr(wgt), ptr(bias), ptr(dst), g, dcode(src.dtype), flags | (4 if need > 0 else 0), ptr(ws), need,
+                          stream()), "ast_igemm")
     if PROFILE is not None:
         e1.record()
         fl, by = _gemm_cost(g, src.element_size())
@@ -314,17 +315,32 @@ class LinearFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------
 # normalisation
 # ---------------------------------------------------------------------------
+_scratch = {}
+
+
+def _clean_scratch(n, device):
+    """Persistent zero-initialised f32 scratch of n floats.  Every kernel pair that uses it (statistics ->
+    finalize, split-K GEMM -> finish) hands it back zeroed, so no launch ever needs a memset.  Work on one
+    stream is serial, so one buffer per size is enough."""
+    key = (n, device)
+    t = _scratch.get(key)
+    if t is None:
+        t = _scratch[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return t
+
+
 def _stats(x):
     N, H, W, C = x.shape
-    sums = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
-    check(lib().ast_chan_stats(ptr(x), ptr(sums), N, H * W, C, dcode(x.dtype), stream()), "ast_chan_stats")
+    sums = _clean_scratch(N * C * 2, x.device)
+    check(lib().ast_chan_stats(ptr(x), ptr(sums), N, H * W, C, dcode(x.dtype), 1, stream()), "ast_chan_stats")
     return sums
 
 
-def _finalize(sums, N, HW, C, Creal, instance, gamma, beta, rm, rv, eval_mode, eps, dev):
+def _finalize(sums, N, HW, C, Creal, instance, gamma, beta, rm, rv, eval_mode, eps, dev, nbt=None):
     n = N * C if instance else C
-    mean, rstd, scale, shift = (torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4))
-    check(lib().ast_norm_finalize(ptr(sums), N, HW, C, Creal, int(instance), ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
+    out = torch.empty((4, n), dtype=torch.float32, device=dev)
+    mean, rstd, scale, shift = out[0], out[1], out[2], out[3]
+    check(lib().ast_norm_finalize(ptr(sums), 1, ptr(nbt), N, HW, C, Creal, int(instance), ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
                                   int(eval_mode), eps, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), stream()),
           "ast_norm_finalize")
     return mean, rstd, scale, shift
@@ -340,8 +356,7 @@ class BatchNormActFn(torch.autograd.Function):
         if training:
             sums = _stats(x)
             mean, rstd, scale, shift = _finalize(sums, N, H * W, C, Creal, False, gamma, beta, bn.running_mean,
-                                                 bn.running_var, False, bn.eps, x.device)
-            bn.num_batches_tracked += 1
+                                                 bn.running_var, False, bn.eps, x.device, nbt=bn.num_batches_tracked)
         else:
             mean, rstd, scale, shift = _finalize(None, N, H * W, C, Creal, False, gamma, beta, bn.running_mean,
                                                  bn.running_var, True, bn.eps, x.device)
@@ -360,11 +375,11 @@ class BatchNormActFn(torch.autograd.Function):
         dy = dy.contiguous()
         N, H, W, C = x.shape
         gamma, beta = ctx.gamma, ctx.beta
-        sums3 = torch.empty((N, C, 3), dtype=torch.float32, device=x.device)
+        sums3 = _clean_scratch(N * C * 3, x.device)
         check(lib().ast_norm_bwd_sums(ptr(dy), ptr(y), ptr(x), None, ptr(sums3), N, H * W, C, int(ctx.relu),
-                                      dcode(x.dtype), stream()), "ast_norm_bwd_sums")
+                                      dcode(x.dtype), 1, stream()), "ast_norm_bwd_sums")
         k1 = torch.empty((C, 3), dtype=torch.float32, device=x.device)
-        check(lib().ast_norm_bwd_finalize(ptr(sums3), N, H * W, C, gamma.numel(), ptr(gamma), ptr(mean), ptr(rstd),
+        check(lib().ast_norm_bwd_finalize(ptr(sums3), 1, N, H * W, C, gamma.numel(), ptr(gamma), ptr(mean), ptr(rstd),
                                           ptr(acc_grad(gamma)), ptr(acc_grad(beta)), ptr(k1),
                                           None, None, None, None, None, None, stream()), "ast_norm_bwd_finalize")
         dx = torch.empty_like(x)
@@ -383,8 +398,7 @@ class ResTailFn(torch.autograd.Function):
         Creal = g1.numel()
         if training:
             m1, r1, s1, f1 = _finalize(_stats(c2), N, H * W, C, Creal, False, g1, b1, bn.running_mean, bn.running_var,
-                                       False, bn.eps, c2.device)
-            bn.num_batches_tracked += 1
+                                       False, bn.eps, c2.device, nbt=bn.num_batches_tracked)
         else:
             m1, r1, s1, f1 = _finalize(None, N, H * W, C, Creal, False, g1, b1, bn.running_mean, bn.running_var,
                                        True, bn.eps, c2.device)
@@ -405,12 +419,12 @@ class ResTailFn(torch.autograd.Function):
         dy = dy.contiguous()
         N, H, W, C = c2.shape
         dev = c2.device
-        sums3 = torch.empty((N, C, 3), dtype=torch.float32, device=dev)
+        sums3 = _clean_scratch(N * C * 3, dev)
         check(lib().ast_norm_bwd_sums(ptr(dy), ptr(y), ptr(c2), ptr(ds), ptr(sums3), N, H * W, C, 1, dcode(c2.dtype),
-                                      stream()), "ast_norm_bwd_sums")
+                                      1, stream()), "ast_norm_bwd_sums")
         k1 = torch.empty((C, 3), dtype=torch.float32, device=dev)
         k2 = torch.empty((N, C, 3), dtype=torch.float32, device=dev)
-        check(lib().ast_norm_bwd_finalize(ptr(sums3), N, H * W, C, g1.numel(), ptr(g1), ptr(m1), ptr(r1),
+        check(lib().ast_norm_bwd_finalize(ptr(sums3), 1, N, H * W, C, g1.numel(), ptr(g1), ptr(m1), ptr(r1),
                                           ptr(acc_grad(g1)), ptr(acc_grad(b1)), ptr(k1), ptr(g2), ptr(m2), ptr(r2),
                                           ptr(acc_grad(g2)), ptr(acc_grad(b2)), ptr(k2), stream()),
               "ast_norm_bwd_finalize")
@@ -564,8 +578,8 @@ class AttnCoreFn(torch.autograd.Function):
         B, H, Lq, Lk, dh, k_off, v_off = ctx.dims
         do = do.contiguous()
         d = H * dh
-        dq = torch.zeros_like(q)
-        dkv = dq if ctx.same else torch.zeros_like(kv)
+        dq = torch.empty_like(q)                    # the kernel writes every q / k / v column of every row
+        dkv = dq if ctx.same else torch.empty_like(kv)
         check(lib().ast_attn_bwd(ptr(do), q.data_ptr(), kv.data_ptr() + 4 * k_off, kv.data_ptr() + 4 * v_off, ptr(probs),
                                  dq.data_ptr(), dkv.data_ptr() + 4 * k_off, dkv.data_ptr() + 4 * v_off, B, H, Lq, Lk, dh,
                                  q.stride(0), kv.stride(0), d, ptr(drop_mask), stream()), "ast_attn_bwd")

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ ws, const float* __restrict__ bias,
                                                             T* __restrict__ dst, const ast_gather_t g, const int M, const int flags) {
   const int c4 = g.Cd >> 2;
   const int HWm = g.Hm * g.Wm;
@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     const int n = m / HWm, rem = m - n * HWm;
     const int hm = rem / g.Wm, wq = rem - hm * g.Wm;
     const size_t pix = (size_t)(n * g.Hd + hm * g.dsh + g.doh) * g.Wd + (wq * g.dsw + g.dow);
-    const f32x4 a = *reinterpret_cast<const f32x4*>(ws + (size_t)m * g.Cd + co);
+    f32x4* wp = reinterpret_cast<f32x4*>(ws + (size_t)m * g.Cd + co);
+    const f32x4 a = *wp;
+    *wp = f32x4{0.f, 0.f, 0.f, 0.f};                  // the workspace is handed back zeroed (no memset per launch)
     float v[4] = {a[0], a[1], a[2], a[3]};
     if (bias) for (int r = 0; r < 4; ++r) v[r] += bias[co + r];
     store4<T>(dst + pix * g.Cd + co, v, flags & 1, flags & 2);
@@ -408,7 +410,7 @@ int launch_igemm(const void* src, const void* wgt, const float* bias, void* dst,
   int shift = -1;
   if ((cpc & (cpc - 1)) == 0) { shift = 0; while ((1 << shift) < cpc) ++shift; }
   dim3 grid((M + BM - 1) / BM, (g.Cd + BN - 1) / BN, p.nsplit);
-  if (p.nsplit > 1) AST_HIP(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)M * g.Cd, s));
+  if (p.nsplit > 1 && !(flags & 4)) AST_HIP(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)M * g.Cd, s));
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KCH>), grid, dim3(256), LDS, s, (const T*)src, (const T*)wgt, bias, (T*)dst, g, M,
                      flags, ws, p.kt_per_split, shift);
   if (p.nsplit > 1) {

@@ -323,7 +323,7 @@ extern "C" int ast_recon_loss(const float* out, const float* tgt, int64_t tgt_ld
   hipStream_t s = (hipStream_t)stream;
   AST_HIP(hipMemsetAsync(sums, 0, 5 * sizeof(float), s));
   const size_t total = (size_t)B * T * Fq;
-  const int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 1024);   // 5 same-address atomics per block: keep the count low
   hipLaunchKernelGGL(recon_loss_kernel, dim3(grid), dim3(256), 0, s, out, tgt, tgt_ld, B, S, T, Fq, c_mse, c_mag, c_phase, c_temporal,
                      c_spectral, sums, grad);
   AST_CHECK_LAUNCH();

@@ -261,6 +261,23 @@ __global__ void colsum_acc_kernel(const T* __restrict__ x, size_t rows, int C, i
   for (size_t r = r0; r < r1; ++r) a += (float)x[r * C + c];
   unsafeAtomicAdd(out + c, a);
 }
+// small C (<= 64): thread = (row lane, column); LDS reduce over row lanes
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__ x, size_t rows, int C, int Creal, float* __restrict__ out,
+                                                            size_t rows_per_blk) {
+  __shared__ float red[256];
+  const int c = threadIdx.x % C, rl = threadIdx.x / C, RL = 256 / C;
+  const size_t r0 = (size_t)blockIdx.x * rows_per_blk, r1 = r0 + rows_per_blk < rows ? r0 + rows_per_blk : rows;
+  float a = 0.f;
+  if (rl < RL) for (size_t r = r0 + rl; r < r1; r += RL) a += (float)x[r * C + c];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < Creal) {
+    float t = 0.f;
+    for (int q = 0; q < RL; ++q) t += red[q * C + threadIdx.x];
+    unsafeAtomicAdd(out + threadIdx.x, t);
+  }
+}
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
 }
@@ -408,6 +425,14 @@ extern "C" int ast_mul(const void* a, const float* mask, void* y, int64_t n, int
 extern "C" int ast_colsum_acc(const void* x, int64_t rows, int C, int Creal, float* out, int dtype, void* stream) {
   if (!x || !out || rows < 0 || C <= 0 || Creal > C) AST_FAIL("ast_colsum_acc: bad args");
   if (rows == 0) return 0;
+  if (C <= 64) {
+    const int nb = (int)std::min<size_t>(512, ((size_t)rows * C + 16383) / 16384);
+    const size_t rpb = ((size_t)rows + nb - 1) / nb;
+    AST_DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_small_kernel<T>), dim3((unsigned)(((size_t)rows + rpb - 1) / rpb)), dim3(256), 0,
+                                              (hipStream_t)stream, (const T*)x, (size_t)rows, C, Creal, out, rpb));
+    AST_CHECK_LAUNCH();
+    return 0;
+  }
   const int bx = C >= 256 ? 256 : 64;
   const int nchunk = (int)std::min<size_t>(1024, ((size_t)rows + 63) / 64);
   const size_t rpb = ((size_t)rows + nchunk - 1) / nchunk;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const T* __restrict__ 
 }
 
 // one wave per output statistic (channel for batch norm, (n,c) for instance norm); lanes stride over images
-__global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ sums, int N, int HW, int C, int Creal, int instance,
+__global__ __launch_bounds__(256) void norm_finalize_kernel(float* __restrict__ sums, int zero_sums, int64_t* nbt, int N, int HW, int C, int Creal, int instance,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float* running_mean, float* running_var, int eval_mode, float eps,
                                      float* __restrict__ mean, float* __restrict__ rstd,
@@ -84,16 +84,22 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restr
   if (idx >= total) return;
   const int c = idx % C;
   float m, var;
+  if (nbt && idx == 0 && lane == 0) nbt[0] += 1;       // BatchNorm2d.num_batches_tracked
   if (instance) {
     const float cnt = (float)HW;
     m = sums[(size_t)idx * 2] / cnt;
     var = fmaxf(sums[(size_t)idx * 2 + 1] / cnt - m * m, 0.f);
+    if (zero_sums && lane == 0) { sums[(size_t)idx * 2] = 0.f; sums[(size_t)idx * 2 + 1] = 0.f; }
   } else if (eval_mode) {
     m = c < Creal ? running_mean[c] : 0.f;
     var = c < Creal ? running_var[c] : 1.f;
   } else {
     float s0 = 0.f, s1 = 0.f;
-    for (int n = lane; n < N; n += 64) { s0 += sums[((size_t)n * C + c) * 2]; s1 += sums[((size_t)n * C + c) * 2 + 1]; }
+    for (int n = lane; n < N; n += 64) {
+      float* q = sums + ((size_t)n * C + c) * 2;
+      s0 += q[0]; s1 += q[1];
+      if (zero_sums) { q[0] = 0.f; q[1] = 0.f; }          // leave the shared statistics scratch clean for the next caller
+    }
     s0 = wave_sum(s0); s1 = wave_sum(s1);
     const double cnt = (double)N * HW;
     const double md = (double)s0 / cnt;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
 }
 
 // k1[c][3] for the batch branch, k2[n][c][3] for the instance branch; one wave per channel, lanes over images
-__global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __restrict__ sums3, int N, int HW, int C, int Creal,
+__global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(float* __restrict__ sums3, int zero_sums, int N, int HW, int C, int Creal,
                                          const float* gamma1, const float* mean1, const float* rstd1,
                                          float* dgamma1, float* dbeta1, float* k1,
                                          const float* gamma2, const float* mean2, const float* rstd2,
@@ -158,10 +164,12 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float* __r
   for (int n = lane; n < N; n += 64) {
     const size_t i = (size_t)n * C + c;
     const float T0 = sums3[i * 3], T1 = sums3[i * 3 + 1];
+    const float T2raw = sums3[i * 3 + 2];
+    if (zero_sums) { sums3[i * 3] = 0.f; sums3[i * 3 + 1] = 0.f; sums3[i * 3 + 2] = 0.f; }
     s0 += T0; s1 += T1;
     if (k2) {
       if (real) {
-        const double T2 = sums3[i * 3 + 2];
+        const double T2 = T2raw;
         const double P = (double)HW, g = gamma2[c], m = mean2[i], r = rstd2[i];
         const double Q = r * (T2 - m * (double)T0);
         dg += (float)Q;
@@ -275,10 +283,10 @@ int grid_for(size_t n, int block = 256) { return (int)std::min<size_t>((n + bloc
 
 }  // namespace
 
-extern "C" int ast_chan_stats(const void* x, float* sums, int N, int HW, int C, int dtype, void* stream) {
+extern "C" int ast_chan_stats(const void* x, float* sums, int N, int HW, int C, int dtype, int assume_zeroed, void* stream) {
   if (!x || !sums || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || C > 2048) AST_FAIL("ast_chan_stats: bad args N=%d HW=%d C=%d", N, HW, C);
   hipStream_t s = (hipStream_t)stream;
-  AST_HIP(hipMemsetAsync(sums, 0, sizeof(float) * (size_t)N * C * 2, s));
+  if (!assume_zeroed) AST_HIP(hipMemsetAsync(sums, 0, sizeof(float) * (size_t)N * C * 2, s));
   const int PL = 256 / (C >> 3);
   const int nblk = max(1, min((HW + PL - 1) / PL, max(1, 2048 / N)));
   const int ppb = (HW + nblk - 1) / nblk;
@@ -289,15 +297,16 @@ extern "C" int ast_chan_stats(const void* x, float* sums, int N, int HW, int C, 
   return 0;
 }
 
-extern "C" int ast_norm_finalize(const float* sums, int N, int HW, int C, int Creal, int instance, const float* gamma,
-                                 const float* beta, float* running_mean, float* running_var, int eval_mode, float eps,
+extern "C" int ast_norm_finalize(float* sums, int zero_sums, int64_t* num_batches_tracked, int N, int HW, int C, int Creal, int instance,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var, int eval_mode, float eps,
                                  float* mean, float* rstd, float* scale, float* shift, void* stream) {
   if (!gamma || !beta || !mean || !rstd || !scale || !shift) AST_FAIL("ast_norm_finalize: null pointer");
   if (!eval_mode && !sums) AST_FAIL("ast_norm_finalize: sums required in training mode");
   if (eval_mode && (instance || !running_mean || !running_var)) AST_FAIL("ast_norm_finalize: eval mode needs running stats");
   const int total = instance ? N * C : C;
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums, N, HW, C,
-                     Creal, instance, gamma, beta, running_mean, running_var, eval_mode, eps, mean, rstd, scale, shift);
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums, zero_sums,
+                     num_batches_tracked, N, HW, C, Creal, instance, gamma, beta, running_mean, running_var, eval_mode, eps, mean, rstd,
+                     scale, shift);
   AST_CHECK_LAUNCH();
   return 0;
 }
@@ -316,10 +325,10 @@ extern "C" int ast_affine_act(const void* x, const float* scale, const float* sh
 }
 
 extern "C" int ast_norm_bwd_sums(const void* dy, const void* y, const void* x, const void* r, float* sums3, int N, int HW,
-                                 int C, int relu, int dtype, void* stream) {
+                                 int C, int relu, int dtype, int assume_zeroed, void* stream) {
   if (!dy || !x || !sums3 || (relu && !y) || (C & 7) || C > 2048) AST_FAIL("ast_norm_bwd_sums: bad args");
   hipStream_t s = (hipStream_t)stream;
-  AST_HIP(hipMemsetAsync(sums3, 0, sizeof(float) * (size_t)N * C * 3, s));
+  if (!assume_zeroed) AST_HIP(hipMemsetAsync(sums3, 0, sizeof(float) * (size_t)N * C * 3, s));
   const int PL = 256 / (C >> 3);
   const int nblk = max(1, min((HW + PL - 1) / PL, max(1, 2048 / N)));
   const int ppb = (HW + nblk - 1) / nblk;
@@ -330,12 +339,12 @@ extern "C" int ast_norm_bwd_sums(const void* dy, const void* y, const void* x, c
   return 0;
 }
 
-extern "C" int ast_norm_bwd_finalize(const float* sums3, int N, int HW, int C, int Creal, const float* gamma1,
+extern "C" int ast_norm_bwd_finalize(float* sums3, int zero_sums, int N, int HW, int C, int Creal, const float* gamma1,
                                      const float* mean1, const float* rstd1, float* dgamma1, float* dbeta1, float* k1,
                                      const float* gamma2, const float* mean2, const float* rstd2, float* dgamma2,
                                      float* dbeta2, float* k2, void* stream) {
   if (!sums3 || (k1 && (!gamma1 || !mean1 || !rstd1)) || (k2 && (!gamma2 || !mean2 || !rstd2))) AST_FAIL("ast_norm_bwd_finalize: bad args");
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums3, N, HW, C, Creal,
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums3, zero_sums, N, HW, C, Creal,
                      gamma1, mean1, rstd1, dgamma1, dbeta1, k1, gamma2, mean2, rstd2, dgamma2, dbeta2, k2);
   AST_CHECK_LAUNCH();
   return 0;

@@ -54,7 +54,8 @@ typedef struct ast_gather_t {
 /* dst[pix][co] (+)= sum_{t,c} src[gather(pix,t)][c] * wgt[co][wtap[t]][c] + bias[co]
  * Replaces: nn.Conv2d fwd/bwd-data (style_encoder.py:50-67, new_decoder.py:29-61),
  * nn.ConvTranspose2d fwd/bwd-data (new_decoder.py:72-96), nn.Linear fwd/bwd-data.
- * flags: bit0 accumulate into dst, bit1 ReLU. */
+ * flags: bit0 accumulate into dst, bit1 ReLU, bit2 the split-K workspace is already zero (the finish pass
+ * always hands it back zeroed, so a persistent workspace never needs a memset). */
 int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst,
               const ast_gather_t* g, int dtype, int flags, float* ws, long ws_floats, void* stream);
 /* f32 workspace (floats) ast_igemm needs for this geometry: >0 when the launch is split over K
@@ -117,11 +118,13 @@ int ast_weight_grad_unpack(const float* dwp, int from_wb, const float* w, const 
                            int Cop, int Cip, float* scratch, void* stream);
 
 /* ---- normalisation (nn.BatchNorm2d / nn.InstanceNorm2d / nn.LayerNorm) ------ */
-/* sums[n][c][k]: k=0 sum x, k=1 sum x^2 over the H*W pixels of image n (buffer zeroed inside). */
-int ast_chan_stats(const void* x, float* sums, int N, int HW, int C, int dtype, void* stream);
+/* sums[n][c][k]: k=0 sum x, k=1 sum x^2 over the H*W pixels of image n.  The buffer is zeroed inside unless
+ * assume_zeroed (a persistent scratch that ast_norm_finalize(zero_sums=1) handed back clean). */
+int ast_chan_stats(const void* x, float* sums, int N, int HW, int C, int dtype, int assume_zeroed, void* stream);
 /* From sums -> per-channel (batch) or per-(n,c) (instance) scale/shift; updates
  * running stats when running_mean != NULL (momentum 0.1, unbiased var). eval_mode uses running stats. */
-int ast_norm_finalize(const float* sums, int N, int HW, int C, int Creal, int instance,
+int ast_norm_finalize(float* sums, int zero_sums, int64_t* num_batches_tracked /* +1 when not NULL */,
+                      int N, int HW, int C, int Creal, int instance,
                       const float* gamma, const float* beta, float* running_mean, float* running_var,
                       int eval_mode, float eps, float* mean, float* rstd, float* scale, float* shift,
                       void* stream);
@@ -133,9 +136,9 @@ int ast_affine_act(const void* x, const float* scale, const float* shift, const 
 /* backward of the above followed by the norm backward:
  * dz = dy * (y>0 if relu); sums3[n][c] = {sum dz, sum dz*x, sum dz*r} */
 int ast_norm_bwd_sums(const void* dy, const void* y, const void* x, const void* r, float* sums3,
-                      int N, int HW, int C, int relu, int dtype, void* stream);
+                      int N, int HW, int C, int relu, int dtype, int assume_zeroed, void* stream);
 /* coefficients k[c][3] (batch branch) and j[n][c][3] (instance branch) and dgamma/dbeta accumulation */
-int ast_norm_bwd_finalize(const float* sums3, int N, int HW, int C, int Creal,
+int ast_norm_bwd_finalize(float* sums3, int zero_sums, int N, int HW, int C, int Creal,
                           const float* gamma1, const float* mean1, const float* rstd1,
                           float* dgamma1, float* dbeta1, float* k1,
                           const float* gamma2, const float* mean2, const float* rstd2,
