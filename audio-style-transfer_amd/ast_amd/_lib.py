@@ -36,6 +36,7 @@ class WeightDesc(C.Structure):
 _SIGS = {
     "ast_version": ([], i32),
     "ast_igemm": ([vp, vp, vp, vp, C.POINTER(Gather), i32, i32, vp, C.c_long, vp], i32),
+    "ast_igemm_plan": ([C.POINTER(Gather), i32, C.POINTER(i32 * 5)], i32),
     "ast_igemm_ws_floats": ([C.POINTER(Gather), i32], C.c_long),
     "ast_wgrad": ([vp, vp, vp, C.POINTER(Gather), i32, vp], i32),
     "ast_skinny_gemm": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),

@@ -84,16 +84,12 @@ def _gemm_cost(g, esize, wgrad=False):
     return flops, nbytes
 
 
-def _igemm_config(g, M):
-    """Mirrors the tile selection in csrc/igemm.hip:ast_igemm (for reporting only)."""
-    t128 = ((M + 127) // 128) * ((g.Cd + 127) // 128)
-    if g.Cd > 64:
-        return "128x128" if t128 >= 384 else "64x64"
-    if g.Cd > 32:
-        return "128x64" if M >= 128 * 512 else "64x64"
-    if g.Cd > 16:
-        return "256x32" if M >= 256 * 512 else "64x32"
-    return "256x16" if M >= 256 * 512 else "64x16"
+def _igemm_config(g, dt):
+    """Tile plan the library picks for this geometry (reporting only)."""
+    import ctypes
+    out = (ctypes.c_int32 * 5)()
+    check(lib().ast_igemm_plan(g, dt, ctypes.byref(out)), "ast_igemm_plan")
+    return f"{out[0]}x{out[1]},k{out[2] * 16}B" + (f",split{out[3]}" if out[3] > 1 else "")
 
 
 _ws_cache = {}
@@ -122,7 +118,7 @@ def _igemm(src, wgt, bias, dst, g, flags=0):
         e1.record()
         fl, by = _gemm_cost(g, src.element_size())
         dt = "bf16" if src.dtype == torch.bfloat16 else "f32"
-        PROFILE.append((f"igemm_kernel<{dt},{_igemm_config(g, g.N * g.Hm * g.Wm)}>", fl, by, e0, e1))
+        PROFILE.append((f"igemm_kernel<{dt},{_igemm_config(g, dcode(src.dtype))}>", fl, by, e0, e1))
 
 
 def _wgrad(dy, src, dwp, g):

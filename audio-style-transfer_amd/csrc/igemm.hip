@@ -57,51 +57,87 @@ __device__ __forceinline__ void store4(T* p, float (&v)[4], bool accumulate, boo
   }
 }
 
-// KCH = 16-byte chunks per row per K tile (4 -> 64 B, 8 -> 128 B): one barrier per tile.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// floor(n / d) for 0 <= n < 2^31 through a float reciprocal (+-1 fix-up); integer division costs ~40 VALU.
+__device__ __forceinline__ int fdiv(int n, int d, float rcp) {
+  if (d == 1) return n;
+  int q = (int)((float)n * rcp);
+  int r = n - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; r -= d; }
+  if (r >= d) ++q;
+  return q;
+}
+
+// LDS image: unpadded 64-byte rows (4 chunks of 16 B); chunk c of row r lives in slot (c + 2*((r>>3)&1)) & 3.
+// With ds_read_b128's 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (lane = row + 16*chunk) this
+// rotation puts the 16 lanes of every group on 16 distinct 16-byte slots of the 256-byte bank row
+// (conflict-free), and 8 consecutive store lanes (2 rows x 4 chunks) still cover 128 contiguous bytes.
+__device__ __forceinline__ int swz(int row, int c) { return ((c + (((row >> 3) & 1) << 1)) & 3) << 4; }
+
+// KCH = 16-byte chunks per row staged per barrier (4 or 8; 8 = two 64-byte sub-tiles).
 // grid.z = split-K slices; with more than one slice the f32 partial tiles are added into `ws`
 // ([M][Cd]) with atomics and splitk_finish_kernel applies bias / accumulate / ReLU / cast.
-template <typename T, int BM, int BN, int WM, int WN, int KCH>
+// Operands are read with buffer_load_dwordx4: masked lanes get an out-of-range offset and the
+// hardware returns zeros (no select, no 64-bit address arithmetic).
+template <typename T, int BM, int BN, int WM, int WN, int KCH, int D>
 __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, const T* __restrict__ wgt,
                                                      const float* __restrict__ bias, T* __restrict__ dst,
                                                      const ast_gather_t g, const int M, const int flags,
-                                                     float* __restrict__ ws, const int kt_per_split, const int cpc_shift) {
+                                                     float* __restrict__ ws, const int kt_per_split, const int cpc_shift,
+                                                     const unsigned src_bytes, const unsigned wgt_bytes,
+                                                     const float rcp_hw, const float rcp_w) {
   constexpr int E = 16 / sizeof(T);
-  constexpr int RB = KCH * 16 + 16;          // LDS row pitch: data + 16 B pad (bank spread for ds_read_b128)
+  constexpr int ES = sizeof(T);
+  constexpr int NSUB = KCH / 4;
   constexpr int RPP = 256 / KCH;             // rows staged per pass
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
   constexpr int AI = BM / RPP, BI = (BN + RPP - 1) / RPP;
+  constexpr int SUBB = (BM + BN) * 64;       // bytes of one sub-tile (A rows then B rows)
+  constexpr unsigned OOB = 0x80000000u;
   static_assert(WM * WN == 4 && BM % RPP == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile");
   using frag = typename Mma<T>::frag;
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // 2 * (BM + BN) * RB, then 16 ints
-  int* taptab = reinterpret_cast<int*>(lds + 2 * (BM + BN) * RB);
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // 2 * NSUB * SUBB, then 16 ints
+  int* taptab = reinterpret_cast<int*>(lds + 2 * NSUB * SUBB);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int cc = tid % KCH, r0 = tid / KCH;
+  const int csub = cc >> 2, cch = cc & 3;
   const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
   const int cpc = g.Cs / E;
   const int nchunks = g.ntaps * cpc;
   const int KT = (nchunks + KCH - 1) / KCH;
   const int kt0 = blockIdx.z * kt_per_split, kt1 = min(KT, kt0 + kt_per_split);
   const int HWm = g.Hm * g.Wm;
+  const __amdgpu_buffer_rsrc_t srcR = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wgtR = __builtin_amdgcn_make_buffer_rsrc((void*)wgt, 0, wgt_bytes, 0x00020000);
 
 #pragma unroll
   for (int t = 0; t < AST_MAX_TAPS; ++t)
     if (tid == t) taptab[t] = g.tap[t];          // static index: a dynamic one would spill the by-value struct to scratch
 
-  RowPix rp[AI];
+  int roff[AI], rhs0[AI], rws0[AI];              // source byte offset of the row's base pixel (negative for halo rows)
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int m = bm0 + r0 + RPP * i;
-    rp[i].valid = m < M;
-    const int mm = rp[i].valid ? m : 0;
-    const int n = mm / HWm, rem = mm - n * HWm;
-    const int hm = rem / g.Wm, wq = rem - hm * g.Wm;
-    rp[i].hs0 = hm * g.sh + g.oh;
-    rp[i].ws0 = wq * g.sw + g.ow;
-    rp[i].off = ((n * g.Hs + rp[i].hs0) * g.Ws + rp[i].ws0) * g.Cs;
+    const bool valid = m < M;
+    const int mm = valid ? m : 0;
+    const int n = fdiv(mm, HWm, rcp_hw), rem = mm - n * HWm;
+    const int hm = fdiv(rem, g.Wm, rcp_w), wq = rem - hm * g.Wm;
+    rhs0[i] = valid ? hm * g.sh + g.oh : -(1 << 20);        // an invalid row fails every bounds test below
+    rws0[i] = wq * g.sw + g.ow;
+    roff[i] = (((n * g.Hs + rhs0[i]) * g.Ws + rws0[i]) * g.Cs) * ES;
+  }
+  unsigned boff[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int row = r0 + RPP * i, co = bn0 + row;
+    boff[i] = (row < BN && co < g.Cd) ? (unsigned)(co * g.wtaps * g.Cs * ES) : OOB;
   }
   __syncthreads();
 
@@ -111,71 +147,77 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 areg[AI], breg[BI];
+  // D-stage register prefetch: the loads of K tile k+D are issued before tile k is consumed, so up to D
+  // tiles are in flight per workgroup (the deep layers run ~1 workgroup per CU and are otherwise
+  // latency-bound).  The K loop is unrolled by D so every stage index is a compile-time constant.
+  u32x4 areg[D][AI], breg[D][BI];
 
-  auto load_tile = [&](int kt) __attribute__((always_inline)) {
+  auto load_tile = [&](int kt, u32x4 (&ar)[AI], u32x4 (&br)[BI]) __attribute__((always_inline)) {
     const int kc = kt * KCH + cc;
-    const bool kval = kc < nchunks;
+    const bool kval = kc < nchunks && kt < kt1;
     const int t = kval ? (cpc_shift >= 0 ? (kc >> cpc_shift) : kc / cpc) : 0;
     const int c0 = (kc - t * cpc) * E;
     int dh, dw, wt;
     decode_tap(taptab[t], dh, dw, wt);
-    const int delta = (dh * g.Ws + dw) * g.Cs + c0;
+    const int delta = ((dh * g.Ws + dw) * g.Cs + c0) * ES;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const bool ok = kval && rp[i].valid && (unsigned)(rp[i].hs0 + dh) < (unsigned)g.Hs &&
-                      (unsigned)(rp[i].ws0 + dw) < (unsigned)g.Ws;
-      // always a valid global address (element 0 when masked) + value select: a conditional
-      // dereference compiles to a FLAT load through a pointer select (ties vmcnt to lgkmcnt)
-      const uint4 v = *reinterpret_cast<const uint4*>(src + (ok ? rp[i].off + delta : 0));
-      areg[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+      const bool ok = kval && (unsigned)(rhs0[i] + dh) < (unsigned)g.Hs && (unsigned)(rws0[i] + dw) < (unsigned)g.Ws;
+      ar[i] = __builtin_amdgcn_raw_buffer_load_b128(srcR, ok ? (unsigned)(roff[i] + delta) : OOB, 0, 0);
     }
-    const int woff = wt * g.Cs + c0;
+    const unsigned woff = (unsigned)((wt * g.Cs + c0) * ES);
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int row = r0 + RPP * i, co = bn0 + row;
-      const bool ok = kval && row < BN && co < g.Cd;
-      const uint4 v = *reinterpret_cast<const uint4*>(wgt + (ok ? (size_t)co * g.wtaps * g.Cs + woff : 0));
-      breg[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
-    }
+    for (int i = 0; i < BI; ++i)
+      br[i] = __builtin_amdgcn_raw_buffer_load_b128(wgtR, (kval && boff[i] != OOB) ? boff[i] + woff : OOB, 0, 0);
   };
-  auto store_tile = [&](int buf) __attribute__((always_inline)) {
-    unsigned char* As = lds + buf * (BM + BN) * RB;
-    unsigned char* Bs = As + BM * RB;
+  auto store_tile = [&](int buf, const u32x4 (&ar)[AI], const u32x4 (&br)[BI]) __attribute__((always_inline)) {
+    unsigned char* base = lds + (buf * NSUB + csub) * SUBB;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) *reinterpret_cast<uint4*>(As + (r0 + RPP * i) * RB + cc * 16) = areg[i];
+    for (int i = 0; i < AI; ++i) {
+      const int row = r0 + RPP * i;
+      *reinterpret_cast<u32x4*>(base + row * 64 + swz(row, cch)) = ar[i];
+    }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int row = r0 + RPP * i;
-      if (row < BN) *reinterpret_cast<uint4*>(Bs + row * RB + cc * 16) = breg[i];
+      if (row < BN) *reinterpret_cast<u32x4*>(base + (BM + row) * 64 + swz(row, cch)) = br[i];
     }
   };
 
   const int fr = lane & 15, fq = lane >> 4;
-  if (kt0 < kt1) {
-    load_tile(kt0);
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    if (kt + 1 < kt1) load_tile(kt + 1);
-    const unsigned char* As = lds + cur * (BM + BN) * RB;
-    const unsigned char* Bs = As + BM * RB;
+  const int fsw = swz(fr, fq);                             // fragment rows are 16-aligned: (row>>3)&1 == (fr>>3)&1
+  int aoffs[TM], boffs[TN];
 #pragma unroll
-    for (int ks = 0; ks < KCH / 4; ++ks) {
-      frag wf[TN], xf[TM];
+  for (int j = 0; j < TM; ++j) aoffs[j] = (wm * WTM + j * 16 + fr) * 64 + fsw;
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const frag*>(Bs + (wn * WTN + i * 16 + fr) * RB + (ks * 4 + fq) * 16);
+  for (int i = 0; i < TN; ++i) boffs[i] = (BM + wn * WTN + i * 16 + fr) * 64 + fsw;
+
 #pragma unroll
-      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const frag*>(As + (wm * WTM + j * 16 + fr) * RB + (ks * 4 + fq) * 16);
+  for (int st = 0; st < D; ++st) load_tile(kt0 + st, areg[st], breg[st]);
+  for (int ktb = kt0; ktb < kt1; ktb += D) {
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+    for (int st = 0; st < D; ++st) {
+      const int kt = ktb + st;
+      if (kt < kt1) {                                        // uniform per workgroup
+        const int cur = (kt - kt0) & 1;
+        store_tile(cur, areg[st], breg[st]);                 // waits (counted vmcnt) for this stage's loads only
+        load_tile(kt + D, areg[st], breg[st]);
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+        for (int ks = 0; ks < NSUB; ++ks) {
+          const unsigned char* base = lds + (cur * NSUB + ks) * SUBB;
+          frag wf[TN], xf[TM];
+#pragma unroll
+          for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const frag*>(base + boffs[i]);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const frag*>(base + aoffs[j]);
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+        }
+      }
     }
-    if (kt + 1 < kt1) store_tile(cur ^ 1);
-    __syncthreads();
   }
 
   // epilogue: lane owns pixel (col) fr of tile j and channels fq*4..fq*4+3 (rows) of tile i
@@ -195,8 +237,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
       }
       continue;
     }
-    const int n = m / HWm, rem = m - n * HWm;
-    const int hm = rem / g.Wm, wq = rem - hm * g.Wm;
+    const int n = fdiv(m, HWm, rcp_hw), rem = m - n * HWm;
+    const int hm = fdiv(rem, g.Wm, rcp_w), wq = rem - hm * g.Wm;
     const size_t pix = (size_t)(n * g.Hd + hm * g.dsh + g.doh) * g.Wd + (wq * g.dsw + g.dow);
     T* drow = dst + pix * g.Cd;
 #pragma unroll
@@ -374,35 +416,47 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dy, co
   }
 }
 
-struct IgemmPlan { int bm, bn, kch, nsplit, kt_per_split; };
+struct IgemmPlan { int bm, bn, kch, nsplit, kt_per_split, depth; };
 
 IgemmPlan plan_igemm(const ast_gather_t& g, int M, int dtype) {
   const int E = dtype == AST_BF16 ? 8 : 4;
   const int nchunks = g.ntaps * (g.Cs / E);
   IgemmPlan p;
-  const long tiles128 = (long)((M + 127) / 128) * ((g.Cd + 127) / 128);
-  if (g.Cd > 64) { if (tiles128 >= 384) { p.bm = 128; p.bn = 128; } else { p.bm = 64; p.bn = 64; } }
-  else if (g.Cd > 32) { if (M >= 128 * 512) { p.bm = 128; p.bn = 64; } else { p.bm = 64; p.bn = 64; } }
-  else if (g.Cd > 16) { p.bn = 32; p.bm = M >= 256 * 512 ? 256 : 64; }
-  else { p.bn = 16; p.bm = M >= 256 * 512 ? 256 : 64; }
+  // tile plan from tools/igemm_sweep.py on MI355X (profiles/r01): 64-row tiles win on every layer of the
+  // B=8 step (more workgroups per CU matter more than operand reuse at these sizes)
+  if (g.Cd > 64) { p.bm = 64; p.bn = (M >= 30000) ? 128 : 64; }
+  else if (g.Cd > 32) { p.bm = 64; p.bn = 64; }
+  else if (g.Cd > 16) { p.bn = 32; p.bm = M >= 4096 ? 128 : 64; }
+  else { p.bn = 16; p.bm = M >= 4096 ? 128 : 64; }
   p.kch = (p.bn >= 64 && nchunks >= 16) ? 8 : 4;
   const int KT = (nchunks + p.kch - 1) / p.kch;
   const long blocks = (long)((M + p.bm - 1) / p.bm) * ((g.Cd + p.bn - 1) / p.bn);
   p.nsplit = 1;
-  if (blocks < 256 && KT >= 8) p.nsplit = (int)std::max(1L, std::min<long>(std::min<long>(KT / 4, 32), (640 + blocks - 1) / blocks));
-  p.kt_per_split = (KT + p.nsplit - 1) / p.nsplit;
-  p.nsplit = KT > 0 ? (KT + p.kt_per_split - 1) / p.kt_per_split : 1;
+  if (blocks < 200 && KT >= 16 && (long)M * g.Cd <= (1L << 20)) p.nsplit = blocks < 120 ? 4 : 2;
+  p.depth = 2;                                          // depth 4 measured no better (the loop is not latency-bound)
+  if (const char* f = getenv("AST_IGEMM_FORCE")) {      // tuning aid: "bm,bn,kch,nsplit[,depth]"
+    int a, b, c, d, e = 0;
+    const int nf = sscanf(f, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &e);
+    if (nf >= 4) { p.bm = a; p.bn = b; p.kch = c; p.nsplit = std::max(1, d); p.depth = 2; }
+    if (nf == 5) p.depth = e;
+  }
+  {
+    const int KT2 = (nchunks + p.kch - 1) / p.kch;
+    p.nsplit = std::max(1, std::min(p.nsplit, std::max(1, KT2)));
+    p.kt_per_split = (KT2 + p.nsplit - 1) / p.nsplit;
+    p.nsplit = KT2 > 0 ? (KT2 + p.kt_per_split - 1) / p.kt_per_split : 1;
+  }
   if (p.kt_per_split < 1) p.kt_per_split = 1;
   return p;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KCH>
+template <typename T, int BM, int BN, int WM, int WN, int KCH, int D>
 int launch_igemm(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t& g, int M, int flags,
                  float* ws, const IgemmPlan& p, hipStream_t s) {
-  constexpr int LDS = 2 * (BM + BN) * (KCH * 16 + 16) + 64;
+  constexpr int LDS = 2 * (KCH / 4) * (BM + BN) * 64 + 64;
   static bool attr_set = false;
   if (!attr_set) {
-    AST_HIP(hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    AST_HIP(hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, KCH, D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   const int E = 16 / sizeof(T);
@@ -411,8 +465,10 @@ int launch_igemm(const void* src, const void* wgt, const float* bias, void* dst,
   if ((cpc & (cpc - 1)) == 0) { shift = 0; while ((1 << shift) < cpc) ++shift; }
   dim3 grid((M + BM - 1) / BM, (g.Cd + BN - 1) / BN, p.nsplit);
   if (p.nsplit > 1 && !(flags & 4)) AST_HIP(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)M * g.Cd, s));
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KCH>), grid, dim3(256), LDS, s, (const T*)src, (const T*)wgt, bias, (T*)dst, g, M,
-                     flags, ws, p.kt_per_split, shift);
+  const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
+  const unsigned wgt_bytes = (unsigned)((size_t)g.Cd * g.wtaps * g.Cs * sizeof(T));
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KCH, D>), grid, dim3(256), LDS, s, (const T*)src, (const T*)wgt, bias, (T*)dst, g, M,
+                     flags, ws, p.kt_per_split, shift, src_bytes, wgt_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm);
   if (p.nsplit > 1) {
     const size_t total = (size_t)M * (g.Cd >> 2);
     hipLaunchKernelGGL((splitk_finish_kernel<T>), dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, s, ws, bias,
@@ -431,8 +487,8 @@ int check_gather(const ast_gather_t* g, const char* who) {
   // destination pixels must stay inside the tensor (a fault here can reset the GPU)
   const long hmax = (long)(g->Hm - 1) * g->dsh + g->doh, wmax = (long)(g->Wm - 1) * g->dsw + g->dow;
   if (g->doh < 0 || g->dow < 0 || hmax >= g->Hd || wmax >= g->Wd) AST_FAIL("%s: destination grid exceeds tensor (%ld,%ld) vs (%d,%d)", who, hmax, wmax, g->Hd, g->Wd);
-  if ((long)g->N * g->Hs * g->Ws * g->Cs >= (1L << 31) || (long)g->N * g->Hm * g->Wm >= (1L << 31) ||
-      (long)g->Cd * g->wtaps * g->Cs >= (1L << 31)) AST_FAIL("%s: tensor exceeds 32-bit element offsets", who);
+  if ((long)g->N * g->Hs * g->Ws * g->Cs * 4 >= (1L << 31) || (long)g->N * g->Hm * g->Wm >= (1L << 31) ||
+      (long)g->Cd * g->wtaps * g->Cs * 4 >= (1L << 31)) AST_FAIL("%s: tensor exceeds the 2 GiB buffer-addressing range", who);
   return 0;
 }
 
@@ -445,6 +501,13 @@ extern "C" long ast_igemm_ws_floats(const ast_gather_t* gp, int dtype) {
   return p.nsplit > 1 ? (long)M * gp->Cd : 0;
 }
 
+extern "C" int ast_igemm_plan(const ast_gather_t* gp, int dtype, int* out5) {
+  if (!gp || !out5 || check_gather(gp, "ast_igemm_plan")) return -1;
+  const IgemmPlan p = plan_igemm(*gp, gp->N * gp->Hm * gp->Wm, dtype);
+  out5[0] = p.bm; out5[1] = p.bn; out5[2] = p.kch; out5[3] = p.nsplit; out5[4] = p.depth;
+  return 0;
+}
+
 extern "C" int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t* gp,
                          int dtype, int flags, float* ws, long ws_floats, void* stream) {
   if (int rc = check_gather(gp, "ast_igemm")) return rc;
@@ -454,11 +517,15 @@ extern "C" int ast_igemm(const void* src, const void* wgt, const float* bias, vo
   hipStream_t s = (hipStream_t)stream;
   IgemmPlan p = plan_igemm(g, M, dtype);
   if (p.nsplit > 1 && (!ws || ws_floats < (long)M * g.Cd)) AST_FAIL("ast_igemm: split-K needs a workspace of %ld floats (ast_igemm_ws_floats)", (long)M * g.Cd);
-#define AST_IG(BM_, BN_, WM_, WN_, K_) return launch_igemm<T, BM_, BN_, WM_, WN_, K_>(src, wgt, bias, dst, g, M, flags, ws, p, s)
+#define AST_IG(BM_, BN_, WM_, WN_, K_) do { if (p.depth >= 4) return launch_igemm<T, BM_, BN_, WM_, WN_, K_, 4>(src, wgt, bias, dst, g, M, flags, ws, p, s); \
+    return launch_igemm<T, BM_, BN_, WM_, WN_, K_, 2>(src, wgt, bias, dst, g, M, flags, ws, p, s); } while (0)
   AST_DISPATCH_T(dtype, {
     if (p.bm == 128 && p.bn == 128) { if (p.kch == 8) AST_IG(128, 128, 2, 2, 8); else AST_IG(128, 128, 2, 2, 4); }
     if (p.bm == 128 && p.bn == 64) { if (p.kch == 8) AST_IG(128, 64, 2, 2, 8); else AST_IG(128, 64, 2, 2, 4); }
     if (p.bm == 64 && p.bn == 64) { if (p.kch == 8) AST_IG(64, 64, 2, 2, 8); else AST_IG(64, 64, 2, 2, 4); }
+    if (p.bm == 64 && p.bn == 128) { if (p.kch == 8) AST_IG(64, 128, 1, 4, 8); else AST_IG(64, 128, 1, 4, 4); }
+    if (p.bm == 128 && p.bn == 32) AST_IG(128, 32, 4, 1, 4);
+    if (p.bm == 128 && p.bn == 16) AST_IG(128, 16, 4, 1, 4);
     if (p.bm == 256 && p.bn == 32) AST_IG(256, 32, 4, 1, 4);
     if (p.bm == 64 && p.bn == 32) AST_IG(64, 32, 4, 1, 4);
     if (p.bm == 256 && p.bn == 16) AST_IG(256, 16, 4, 1, 4);

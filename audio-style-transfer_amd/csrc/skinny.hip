@@ -56,20 +56,48 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
   }
 }
 
-// dW[n][k] += sum_m dy[m][n] x[m][k] ; db[n] += sum_m dy[m][n].  block = (one n, 256 k's)
+// dW[n][k] += sum_m dy[m][n] x[m][k] ; db[n] += sum_m dy[m][n]   (contraction over the <= 64 token rows).
+// One wave = 16 n x 64 k of dW on v_mfma_f32_16x16x4_f32: A[i][g] = dy[4s+g][n0+i], B[g][j] = x[4s+g][k0+j]
+// (16 lanes read 16 consecutive floats), the A fragment reused by 4 k-tiles.
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             float* __restrict__ dW, float* __restrict__ db, int M, int N, int K,
                                                             int lddy, int ldw) {
-  const int n = blockIdx.y;
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  float a = 0.f, bsum = 0.f;
-  for (int m = 0; m < M; ++m) {
-    const float g = dy[(size_t)m * lddy + n];
-    bsum += g;
-    if (k < K) a += g * x[(size_t)m * K + k];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int n0 = (blockIdx.y * 4 + wave) * 16, k0 = blockIdx.x * 64;
+  if (n0 >= N) return;
+  const bool nv = n0 + i < N;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  for (int m = g; m < ((M + 3) & ~3); m += 4) {
+    const bool mv = m < M;
+    const float a = (mv && nv) ? dy[(size_t)m * lddy + n0 + i] : 0.f;
+    bsum += a;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = k0 + t * 16 + i;
+      const float b = (mv && k < K) ? x[(size_t)m * K + k] : 0.f;
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+    }
   }
-  if (k < K) dW[(size_t)n * ldw + k] += a;
-  if (db && k == 0) db[n] += bsum;
+  // D[row = n0 + 4 g + r][col = k0 + 16 t + i]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int k = k0 + t * 16 + i;
+    if (k >= K) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * g + r;
+      if (n < N) dW[(size_t)n * ldw + k] += acc[t][r];
+    }
+  }
+  if (db && blockIdx.x == 0) {
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (g == 0 && nv) db[n0 + i] += bsum;
+  }
 }
 }  // namespace
 
@@ -86,7 +114,7 @@ extern "C" int ast_skinny_gemm(const float* x, const float* w, const float* bias
 extern "C" int ast_linear_wgrad(const float* dy, const float* x, float* dW, float* db, int M, int N, int K, int lddy, int ldw,
                                 void* stream) {
   if (!dy || !x || !dW || M < 1 || N < 1 || K < 1) AST_FAIL("ast_linear_wgrad: bad args");
-  hipLaunchKernelGGL(linear_wgrad_kernel, dim3((K + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, dy, x, dW, db, M, N, K, lddy, ldw);
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, x, dW, db, M, N, K, lddy, ldw);
   AST_CHECK_LAUNCH();
   return 0;
 }
