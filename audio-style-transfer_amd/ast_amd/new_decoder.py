@@ -131,9 +131,18 @@ class Decoder(nn.Module):
             tgt = lyr(tgt, memory, self.training)
         return tgt
 
-    def _training_pass(self, y, memory):
+    def encode_target(self, y):
+        """Teacher-forcing embeddings of the target sections (new_decoder.py:246-248).  Independent of the
+        encoders, so the trainer runs it on its own stream; pass the result to forward(y_embeddings=...)."""
+        self._prepare()
         B, S = y.shape[:2]
-        emb = self._encode_nhwc(ops.nchw_to_nhwc(y.view(B * S, *y.shape[2:]), L.img_dtype())).view(B, S, self.d_model)
+        return self._encode_nhwc(ops.nchw_to_nhwc(y.view(B * S, *y.shape[2:]), L.img_dtype())).view(B, S, self.d_model)
+
+    def _training_pass(self, y, memory, y_embeddings=None):
+        B, S = y.shape[:2]
+        emb = y_embeddings
+        if emb is None:
+            emb = self._encode_nhwc(ops.nchw_to_nhwc(y.view(B * S, *y.shape[2:]), L.img_dtype())).view(B, S, self.d_model)
         tgt = torch.cat([self.start_token.expand(B, 1, -1), emb[:, :-1, :]], dim=1)
         tgt = L.layer_norm(self.pos_encoding(tgt), self.input_norm)
         return self._generate(self._stack(tgt, memory))
@@ -160,14 +169,15 @@ class Decoder(nn.Module):
         self._prepare()
         return self._inference_pass(memory, target_length)
 
-    def forward(self, content_emb, class_emb, y=None, target_length=None):
-        """new_decoder.py:321-345."""
-        self._prepare()
+    def forward(self, content_emb, class_emb, y=None, target_length=None, y_embeddings=None):
+        """new_decoder.py:321-345 (+ optional precomputed encode_target(y))."""
+        if y_embeddings is None or not (self.training and y is not None):
+            self._prepare()
         memory = self._memory(content_emb, class_emb)
         if self.training and y is not None:
             if len(y.shape) != 5:
                 raise ValueError(f"Expected y to have shape [B, S, 2, 287, 513], got {y.shape}")
-            return self._training_pass(y, memory)
+            return self._training_pass(y, memory, y_embeddings)
         return self._inference_pass(memory, target_length)
 
 

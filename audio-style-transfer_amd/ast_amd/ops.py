@@ -317,8 +317,8 @@ _scratch = {}
 def _clean_scratch(n, device):
     """Persistent zero-initialised f32 scratch of n floats.  Every kernel pair that uses it (statistics ->
     finalize, split-K GEMM -> finish) hands it back zeroed, so no launch ever needs a memset.  Work on one
-    stream is serial, so one buffer per size is enough."""
-    key = (n, device)
+    stream is serial, so one buffer per (size, stream) is enough."""
+    key = (n, device, torch.cuda.current_stream(device).cuda_stream)    # streams run concurrently: one scratch each
     t = _scratch.get(key)
     if t is None:
         t = _scratch[key] = torch.zeros(n, dtype=torch.float32, device=device)

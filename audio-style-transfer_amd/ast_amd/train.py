@@ -45,6 +45,7 @@ class TrainConfig:
     use_nce: bool = True
     use_adv: bool = True
     use_graph: bool = True
+    multi_stream: bool = True     # style encoder / content encoder / decoder target-encoder on separate HIP streams
     dropout: bool = True          # nn.Dropout(0.1) as constructed by the reference
 
 
@@ -120,6 +121,8 @@ class Trainer:
         self.G = FlatGroup([self.style, self.content, self.decoder], self.device)
         self.D = FlatGroup([self.disc], self.device)
         self._graphs = {}
+        self._streams = None
+        self._y_emb = None
         self._static = None
         self.losses = {}
 
@@ -132,8 +135,31 @@ class Trainer:
             ops._DropState.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         check(lib().ast_counter_incr(ptr(ops._DropState.counter), stream()), "ast_counter_incr")
         y = x[..., :513]
-        style_emb, class_emb = self.style(x, labels_host)
-        content_emb = self.content(x)
+        y_emb = None
+        if c.multi_stream:
+            # three mutually independent CNN branches: run them concurrently (forward here; autograd replays
+            # each node's backward on the stream of its forward, so backward overlaps the same way)
+            main = torch.cuda.current_stream()
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+            s1, s2, s3 = self._streams
+            ops.cached_nhwc(x, config.compute_dtype)          # shared input conversion, before the fork
+            for st in self._streams:
+                st.wait_stream(main)
+            with torch.cuda.stream(s1):
+                style_emb, class_emb = self.style(x, labels_host)
+            with torch.cuda.stream(s2):
+                content_emb = self.content(x)
+            with torch.cuda.stream(s3):
+                y_emb = self.decoder.encode_target(y)
+            for st in self._streams:
+                main.wait_stream(st)
+            for t in (style_emb, class_emb, content_emb, y_emb):
+                t.record_stream(main)
+        else:
+            style_emb, class_emb = self.style(x, labels_host)
+            content_emb = self.content(x)
+        self._y_emb = y_emb
         # ---- D phase (losses.py:69-79 compute_for_discriminator=True)
         bank_d = _module_bank(self.disc)
         bank_d.prepare(True)
@@ -146,7 +172,7 @@ class Trainer:
     def _g_phase(self, x, y, labels_host, style_emb, class_emb, content_emb):
         c = self.cfg
         idx = ops.const_tensor(tuple(int(v) for v in labels_host.tolist()), torch.long, self.device)
-        out = self.decoder(content_emb, class_emb.index_select(0, idx), y=y)
+        out = self.decoder(content_emb, class_emb.index_select(0, idx), y=y, y_embeddings=self._y_emb)
         rec = compute_comprehensive_loss(out, y)
         total = c.w_rec * rec["total_loss"]
         parts = {"rec": rec["total_loss"].detach()}
@@ -202,7 +228,21 @@ class Trainer:
         self.losses = outs
         return outs
 
+    def _mutable_state(self):
+        ts = [self.G.flat_p, self.G.m, self.G.v, self.G.step, self.D.flat_p, self.D.m, self.D.v, self.D.step]
+        for m in (self.style, self.content, self.decoder, self.disc):
+            ts += list(m.buffers())            # BN running stats / num_batches_tracked, spectral-norm u and v
+        if ops._DropState.counter is not None:
+            ts.append(ops._DropState.counter)
+        return ts
+
     def _capture(self, key, x, labels_host):
+        """Warm-up (allocations, weight banks, constants) + capture.  Warm-up steps are real steps, so every
+        piece of mutable training state is snapshotted first and restored afterwards: capturing is side-effect free."""
+        if ops._DropState.counter is None or ops._DropState.counter.device != self.device:
+            ops._DropState.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        state = self._mutable_state()
+        saved = [t.clone() for t in state]
         static_x = x.clone()
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
@@ -214,6 +254,9 @@ class Trainer:
         gph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gph):
             outs = self._step_body(static_x, labels_host)
+        with torch.no_grad():
+            for t, sv in zip(state, saved):
+                t.copy_(sv)
         self._graphs[key] = (gph, static_x, outs)
 
 

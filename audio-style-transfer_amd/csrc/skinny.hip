@@ -15,6 +15,7 @@ namespace {
 // so each lane ends up with 4 consecutive n of one token row m -> one 16-byte store.  Lane (i = l&15, g = l>>4)
 // loads 16 B of row i at k = kb + 16 s + 4 g: the four MFMAs of a step contract k = 4 g + e over g (e = 0..3),
 // the same k permutation on both operands.
+template <int NS>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int M, int N,
                                                            int K, int ldx, int ldw, int ldy, int relu) {
@@ -22,22 +23,27 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
-  const int kslice = ((K + 63) / 64) * 16;            // k per wave, multiple of 16
+  constexpr int kslice = NS * 16;                     // k per wave (host: 4 * kslice >= K)
   const int kb = wave * kslice;
   const bool nv = n0 + i < N, mv = m0 + i < M;
   const float* wr = w + (size_t)(nv ? n0 + i : 0) * ldw;
   const float* xr = x + (size_t)(mv ? m0 + i : 0) * ldx;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int s = 0; s < kslice; s += 16) {
-    const int k = kb + s + 4 * g;
-    const bool kv = k < K;
-    const f32x4 wl = *reinterpret_cast<const f32x4*>(wr + (kv ? k : 0));
-    const f32x4 xl = *reinterpret_cast<const f32x4*>(xr + (kv ? k : 0));
-    const bool wok = kv && nv, xok = kv && mv;
+  f32x4 wl[NS], xl[NS];                               // every load of the wave's K slice is issued before the first MFMA
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wok ? wl[e] : 0.f, xok ? xl[e] : 0.f, acc, 0, 0, 0);
+  for (int s = 0; s < NS; ++s) {
+    const int k = kb + s * 16 + 4 * g;
+    const bool kv = k < K;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 a = *reinterpret_cast<const f32x4*>(wr + (kv ? k : 0));
+    const f32x4 b = *reinterpret_cast<const f32x4*>(xr + (kv ? k : 0));
+    wl[s] = (kv && nv) ? a : z;
+    xl[s] = (kv && mv) ? b : z;
   }
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s][e], xl[s][e], acc, 0, 0, 0);
   part[wave][lane] = acc;
   __syncthreads();
   if (wave != 0) return;
@@ -59,6 +65,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
 // dW[n][k] += sum_m dy[m][n] x[m][k] ; db[n] += sum_m dy[m][n]   (contraction over the <= 64 token rows).
 // One wave = 16 n x 64 k of dW on v_mfma_f32_16x16x4_f32: A[i][g] = dy[4s+g][n0+i], B[g][j] = x[4s+g][k0+j]
 // (16 lanes read 16 consecutive floats), the A fragment reused by 4 k-tiles.
+template <int MS>
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             float* __restrict__ dW, float* __restrict__ db, int M, int N, int K,
                                                             int lddy, int ldw) {
@@ -71,16 +78,26 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  for (int m = g; m < ((M + 3) & ~3); m += 4) {
+  float av[MS], bv[MS][4];                            // all <= 64 token rows are loaded before the first MFMA
+#pragma unroll
+  for (int st = 0; st < MS; ++st) {
+    const int m = st * 4 + g;
     const bool mv = m < M;
-    const float a = (mv && nv) ? dy[(size_t)m * lddy + n0 + i] : 0.f;
-    bsum += a;
+    const float a = dy[(size_t)(mv ? m : 0) * lddy + (nv ? n0 + i : 0)];
+    av[st] = (mv && nv) ? a : 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int k = k0 + t * 16 + i;
-      const float b = (mv && k < K) ? x[(size_t)m * K + k] : 0.f;
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+      const bool kv = mv && k < K;
+      const float b = x[(size_t)(kv ? m : 0) * K + (kv ? k : 0)];
+      bv[st][t] = kv ? b : 0.f;
     }
+  }
+#pragma unroll
+  for (int st = 0; st < MS; ++st) {
+    bsum += av[st];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv[st][t], acc[t], 0, 0, 0);
   }
   // D[row = n0 + 4 g + r][col = k0 + 16 t + i]
 #pragma unroll
@@ -105,8 +122,14 @@ extern "C" int ast_skinny_gemm(const float* x, const float* w, const float* bias
                                int relu, void* stream) {
   if (!x || !w || !y || M < 1 || M > 64 || N < 1 || K < 4 || (K & 3) || (ldw & 3)) AST_FAIL("ast_skinny_gemm: bad args M=%d N=%d K=%d", M, N, K);
   if ((((uintptr_t)x) | ((uintptr_t)w)) & 15) AST_FAIL("ast_skinny_gemm: operands must be 16-byte aligned");
-  hipLaunchKernelGGL(skinny_gemm_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, M, N, K, K,
-                     ldw, ldy, relu);
+  const int steps = (K + 63) / 64;                    // 16-wide K steps per wave (4 waves split K)
+  dim3 grid((N + 15) / 16, (M + 15) / 16);
+  hipStream_t s = (hipStream_t)stream;
+  if (steps <= 2) hipLaunchKernelGGL(skinny_gemm_kernel<2>, grid, dim3(256), 0, s, x, w, bias, y, M, N, K, K, ldw, ldy, relu);
+  else if (steps <= 4) hipLaunchKernelGGL(skinny_gemm_kernel<4>, grid, dim3(256), 0, s, x, w, bias, y, M, N, K, K, ldw, ldy, relu);
+  else if (steps <= 8) hipLaunchKernelGGL(skinny_gemm_kernel<8>, grid, dim3(256), 0, s, x, w, bias, y, M, N, K, K, ldw, ldy, relu);
+  else if (steps <= 16) hipLaunchKernelGGL(skinny_gemm_kernel<16>, grid, dim3(256), 0, s, x, w, bias, y, M, N, K, K, ldw, ldy, relu);
+  else AST_FAIL("ast_skinny_gemm: K=%d too large for the token path (<= 1024)", K);
   AST_CHECK_LAUNCH();
   return 0;
 }
@@ -114,7 +137,12 @@ extern "C" int ast_skinny_gemm(const float* x, const float* w, const float* bias
 extern "C" int ast_linear_wgrad(const float* dy, const float* x, float* dW, float* db, int M, int N, int K, int lddy, int ldw,
                                 void* stream) {
   if (!dy || !x || !dW || M < 1 || N < 1 || K < 1) AST_FAIL("ast_linear_wgrad: bad args");
-  hipLaunchKernelGGL(linear_wgrad_kernel, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, x, dW, db, M, N, K, lddy, ldw);
+  if (M > 64) AST_FAIL("ast_linear_wgrad: M=%d > 64 token rows", M);
+  dim3 grid((K + 63) / 64, (N + 63) / 64);
+  hipStream_t s = (hipStream_t)stream;
+  if (M <= 16) hipLaunchKernelGGL(linear_wgrad_kernel<4>, grid, dim3(256), 0, s, dy, x, dW, db, M, N, K, lddy, ldw);
+  else if (M <= 32) hipLaunchKernelGGL(linear_wgrad_kernel<8>, grid, dim3(256), 0, s, dy, x, dW, db, M, N, K, lddy, ldw);
+  else hipLaunchKernelGGL(linear_wgrad_kernel<16>, grid, dim3(256), 0, s, dy, x, dW, db, M, N, K, lddy, ldw);
   AST_CHECK_LAUNCH();
   return 0;
 }
