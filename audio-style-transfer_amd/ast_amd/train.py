@@ -45,6 +45,7 @@ class TrainConfig:
     use_nce: bool = True
     use_adv: bool = True
     use_graph: bool = True
+    segmented: bool = False       # capture the step as 3 graphs (what world > 1 uses); for testing on one GPU
     multi_stream: bool = True     # style encoder / content encoder / decoder target-encoder on separate HIP streams
     dropout: bool = True          # nn.Dropout(0.1) as constructed by the reference
 
@@ -123,6 +124,8 @@ class Trainer:
         self._graphs = {}
         self._streams = None
         self._y_emb = None
+        self._carry = None
+        self._parts = None
         self._static = None
         self.losses = {}
 
@@ -197,34 +200,55 @@ class Trainer:
         parts["total"] = total.detach()
         return parts
 
-    def _step_body(self, x, labels_host):
+    # The step as three segments; the data-parallel gradient all-reduces sit between them.
+    def _seg_a(self, x, labels_host):
+        self._carry = self._forward_backward(x, labels_host)          # zero grads, encoders fwd, D-phase fwd+bwd
+
+    def _seg_b(self, x, labels_host):
         c = self.cfg
-        y, style_emb, class_emb, content_emb, d_loss = self._forward_backward(x, labels_host)
-        self.D.all_reduce(self.world)
+        y, style_emb, class_emb, content_emb, d_loss = self._carry
         self.D.adam(c.lr_d, c.betas, c.eps, c.max_grad_norm)
         self.D.zero_grad()
-        parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb)
-        self.G.all_reduce(self.world)
+        self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb)
+        self._parts["adv_d"] = d_loss.detach()
+        self._carry = None
+
+    def _seg_c(self, x, labels_host):
+        c = self.cfg
         self.G.adam(c.lr_g, c.betas, c.eps, c.max_grad_norm)
-        parts["adv_d"] = d_loss.detach()
-        return parts
+
+    def _step_body(self, x, labels_host):
+        self._seg_a(x, labels_host)
+        self.D.all_reduce(self.world)
+        self._seg_b(x, labels_host)
+        self.G.all_reduce(self.world)
+        self._seg_c(x, labels_host)
+        return self._parts
 
     # ------------------------------------------------------------------ public API
     def step(self, x: torch.Tensor, labels_host: torch.Tensor):
         """x: (B,S,2,287,597) f32 on the device; labels on the HOST (balanced [0]*B/2+[1]*B/2 as
         dataloader.py:143-146 builds them).  Returns a dict of detached device scalars."""
         assert not labels_host.is_cuda, "pass labels on the host: avoids a device sync per step"
-        use_graph = self.cfg.use_graph and self.world == 1
-        if not use_graph:
+        if not self.cfg.use_graph:
             self.losses = self._step_body(x, labels_host)
             return self.losses
-        key = (tuple(x.shape), tuple(labels_host.tolist()), config.compute_dtype, self.cfg.use_nce, self.cfg.use_hsic, self.cfg.use_adv)
+        segmented = self.world > 1 or self.cfg.segmented
+        key = (tuple(x.shape), tuple(labels_host.tolist()), config.compute_dtype, self.cfg.use_nce, self.cfg.use_hsic,
+               self.cfg.use_adv, segmented)
         if key not in self._graphs:
-            self._capture(key, x, labels_host)
-        gph, static_x, outs = self._graphs[key]
+            self._capture(key, x, labels_host, segmented)
+        graphs, static_x, outs = self._graphs[key]
         if static_x.data_ptr() != x.data_ptr():
             static_x.copy_(x)
-        gph.replay()
+        if not segmented:
+            graphs[0].replay()
+        else:                                   # data parallel: the two flat-gradient all-reduces run between replays
+            graphs[0].replay()
+            self.D.all_reduce(self.world)
+            graphs[1].replay()
+            self.G.all_reduce(self.world)
+            graphs[2].replay()
         self.losses = outs
         return outs
 
@@ -236,7 +260,7 @@ class Trainer:
             ts.append(ops._DropState.counter)
         return ts
 
-    def _capture(self, key, x, labels_host):
+    def _capture(self, key, x, labels_host, segmented=False):
         """Warm-up (allocations, weight banks, constants) + capture.  Warm-up steps are real steps, so every
         piece of mutable training state is snapshotted first and restored afterwards: capturing is side-effect free."""
         if ops._DropState.counter is None or ops._DropState.counter.device != self.device:
@@ -251,13 +275,27 @@ class Trainer:
                 self._step_body(static_x, labels_host)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        gph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gph):
-            outs = self._step_body(static_x, labels_host)
+        if not segmented:
+            gph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gph):
+                outs = self._step_body(static_x, labels_host)
+            graphs = [gph]
+        else:
+            # three graphs over ONE memory pool: the autograd graph built while capturing segment A is walked
+            # while capturing segment B, so B must see A's activations at the same addresses
+            graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
+            pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(graphs[0], pool=pool):
+                self._seg_a(static_x, labels_host)
+            with torch.cuda.graph(graphs[1], pool=pool):
+                self._seg_b(static_x, labels_host)
+            with torch.cuda.graph(graphs[2], pool=pool):
+                self._seg_c(static_x, labels_host)
+            outs = self._parts
         with torch.no_grad():
             for t, sv in zip(state, saved):
                 t.copy_(sv)
-        self._graphs[key] = (gph, static_x, outs)
+        self._graphs[key] = (graphs, static_x, outs)
 
 
 def synthetic_batch(B, S, device, seed=1000):

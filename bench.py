@@ -124,9 +124,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        backend = os.environ.get("AST_DIST_BACKEND", "nccl")      # "gloo" only for rehearsing ranks on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if os.environ.get("AST_ONE_GPU"):          # rehearsal: all ranks on cuda:0
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
 

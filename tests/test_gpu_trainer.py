@@ -13,9 +13,9 @@ if torch.cuda.is_available():
     from ast_amd import train
 
 
-def _run(use_graph, multi_stream, steps=3):
+def _run(use_graph, multi_stream, steps=3, segmented=False):
     ast_amd.set_compute_dtype(torch.float32)
-    tr = train.Trainer(train.TrainConfig(use_graph=use_graph, multi_stream=multi_stream, dropout=False), seed=7)
+    tr = train.Trainer(train.TrainConfig(use_graph=use_graph, multi_stream=multi_stream, dropout=False, segmented=segmented), seed=7)
     x, labels = train.synthetic_batch(4, 1, "cuda:0", seed=3)
     hist = []
     for _ in range(steps):
@@ -30,7 +30,7 @@ def test_trainer_modes_agree():
     assert all(math.isfinite(v) for h in ref_hist for v in h.values())
     assert ref_hist[0]["total"] != ref_hist[-1]["total"]           # the optimiser actually moves the weights
     assert int(tr0.G.step) == len(ref_hist) and int(tr0.D.step) == len(ref_hist)
-    for mode in ((False, True), (True, True)):
+    for mode in ((False, True, 3, False), (True, True, 3, False), (True, True, 3, True)):   # last: the 3-graph form DP uses
         hist, s, a, _ = _run(*mode)
         for i, (h, r) in enumerate(zip(hist, ref_hist)):
             tol = 2e-4 if i == 0 else 5e-3        # f32-atomic summation order differs run to run and compounds over steps
