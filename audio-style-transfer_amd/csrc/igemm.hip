@@ -280,140 +280,197 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
 
 // ---------------------------------------------------------------------------
 // weight gradient: dw[cd][wtap][c] += sum_pix dy[pix][cd] * src[gather(pix,tap)][c]
-// Block tile 64 (cd) x 64 (columns of the (tap,c) space), K = pixels, split over
-// grid.z; partial tiles are added with f32 atomics (dw is zeroed by the caller).
-// LDS holds [pixel][channel] images as loaded (channels contiguous); the MFMA
-// operands need [channel][pixel], which bf16 gets from ds_read_b64_tr_b16 (hardware
-// transpose read) and f32 from plain ds_read_b32 (one element per lane per MFMA).
+// A workgroup owns BMW output channels x NCT*16 columns of the (tap, channel) space -- ALL columns
+// when they fit (<= 320), so dy is read once instead of once per 64-column tile -- and a slice of the
+// pixels (grid.z); partial tiles are added with f32 atomics (dw is zeroed by the caller).
+// Per K tile (BKP pixels) a thread decodes ONE pixel row and fetches its strided set of 16-byte
+// chunks with buffer loads (hardware zero-fill outside the image).  LDS holds [pixel][channel]
+// images; the MFMA operands need [channel][pixel]: bf16 through ds_read_b64_tr_b16 (hardware
+// transpose), f32 through ds_read_b32 (one element per lane per MFMA).
 // ---------------------------------------------------------------------------
 template <typename T> struct WgradCfg;
-template <> struct WgradCfg<bf16_t> { static constexpr int BKP = 32, PITCH = 64 + 8; };   // elements
-template <> struct WgradCfg<float> { static constexpr int BKP = 16, PITCH = 64 + 16; };
+template <> struct WgradCfg<bf16_t> { static constexpr int BKP = 64, PAD = 8; };    // elements
+template <> struct WgradCfg<float> { static constexpr int BKP = 32, PAD = 16; };
 
-template <typename T>
+template <typename T, int BMW, int NCT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ src,
                                                      float* __restrict__ dw, const ast_gather_t g,
-                                                     const int P, const int pps) {
-  constexpr int E = 16 / sizeof(T);
-  constexpr int BKP = WgradCfg<T>::BKP, PITCH = WgradCfg<T>::PITCH;
-  constexpr int CPR = 64 / E;            // 16-byte chunks per 64-channel row
-  constexpr int RPP = 256 / CPR;         // rows loaded per pass
-  constexpr int NP = BKP / RPP;          // passes per tile (== 1 for both dtypes)
-  static_assert(NP == 1, "one pass per K tile");
-  __shared__ __attribute__((aligned(16))) T Ys[2][BKP * PITCH];
-  __shared__ __attribute__((aligned(16))) T Xs[2][BKP * PITCH];
-  __shared__ int taptab[AST_MAX_TAPS];
+                                                     const int P, const int pps, const unsigned dy_bytes,
+                                                     const unsigned src_bytes, const float rcp_hw, const float rcp_w) {
+  constexpr int E = 16 / sizeof(T), ES = sizeof(T);
+  constexpr int BKP = WgradCfg<T>::BKP, PAD = WgradCfg<T>::PAD;
+  constexpr int BNW = NCT * 16;
+  constexpr int TPR = 256 / BKP;                    // threads per pixel row
+  constexpr int CPX = BNW / E, CPY = BMW / E;       // 16-byte chunks per row
+  constexpr int NXI = (CPX + TPR - 1) / TPR, NYI = (CPY + TPR - 1) / TPR;
+  constexpr int PX = BNW + PAD, PY = BMW + PAD;     // LDS pitches (elements)
+  constexpr int RT = BMW / 16;                      // row (cd) tiles, all handled by every wave
+  constexpr int CTW = (NCT + 3) / 4;                // column tiles per wave
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
+  T* Ys = reinterpret_cast<T*>(wl);
+  T* Xs = Ys + BKP * PY;
+  int* taptab = reinterpret_cast<int*>(Xs + BKP * PX);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;          // 2x2 waves, 32x32 each
-  const int cd0 = blockIdx.x * 64, col0 = blockIdx.y * 64;
+  const int cd0 = blockIdx.x * BMW, col0 = blockIdx.y * BNW;
   const int ncols = g.ntaps * g.Cs;
   const int HWm = g.Hm * g.Wm;
   const int p_begin = blockIdx.z * pps, p_end = min(P, p_begin + pps);
+  const __amdgpu_buffer_rsrc_t dyR = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srcR = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, src_bytes, 0x00020000);
 #pragma unroll
   for (int t = 0; t < AST_MAX_TAPS; ++t)
-    if (tid == t) taptab[t] = g.tap[t];          // static index: a dynamic one would spill the by-value struct to scratch
+    if (tid == t) taptab[t] = g.tap[t];
   __syncthreads();
 
-  // loader role: row = pixel within tile, chunk = 16-byte column chunk
-  const int lrow = tid / CPR, lchunk = tid % CPR;
-  const int ycd = cd0 + lchunk * E;                  // dy channel of this thread's chunk
-  const bool yok = ycd < g.Cd;
-  const int xcol = col0 + lchunk * E;                // column in (tap, c) space
-  const bool xok = xcol < ncols;
-  int dh = 0, dw_ = 0, wt = 0, xc0 = 0;
-  if (xok) { const int t = xcol / g.Cs; xc0 = xcol - t * g.Cs; decode_tap(taptab[t], dh, dw_, wt); }
-
-  uint4 yreg, xreg;
+  // loader role: one pixel row per thread, chunks tq, tq + TPR, ...
+  const int lrow = tid / TPR, tq = tid % TPR;
+  int xdelta[NXI], xdh[NXI], xdw[NXI];              // per chunk slot: byte delta of (tap, channel), tap offsets; dh = 1<<20 marks "no column"
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) {
+    const int ch = tq + TPR * i, col = col0 + ch * E;
+    xdelta[i] = 0; xdh[i] = 1 << 20; xdw[i] = 0;
+    if (ch < CPX && col < ncols) {
+      const int t = col / g.Cs, c = col - t * g.Cs;
+      int dh, dw_, wt;
+      decode_tap(taptab[t], dh, dw_, wt);
+      xdh[i] = dh; xdw[i] = dw_;
+      xdelta[i] = ((dh * g.Ws + dw_) * g.Cs + c) * ES;
+    }
+  }
+  u32x4 yreg[NYI], xreg[NXI];
   auto load_tile = [&](int p0) __attribute__((always_inline)) {
     const int p = p0 + lrow;
     const bool pv = p < p_end;
-    const bool yv = pv && yok;
-    const uint4 yl = *reinterpret_cast<const uint4*>(dy + (yv ? (size_t)p * g.Cd + ycd : 0));
-    yreg = yv ? yl : make_uint4(0u, 0u, 0u, 0u);
     const int pp = pv ? p : 0;
-    const int n = pp / HWm, rem = pp - n * HWm;
-    const int hm = rem / g.Wm, wq = rem - hm * g.Wm;
-    const int hs = hm * g.sh + g.oh + dh, ws = wq * g.sw + g.ow + dw_;
-    const bool xv = pv && xok && (unsigned)hs < (unsigned)g.Hs && (unsigned)ws < (unsigned)g.Ws;
-    const uint4 xl = *reinterpret_cast<const uint4*>(src + (xv ? (size_t)((n * g.Hs + hs) * g.Ws + ws) * g.Cs + xc0 : 0));
-    xreg = xv ? xl : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int i = 0; i < NYI; ++i) {
+      const int ch = tq + TPR * i, cd = cd0 + ch * E;
+      const bool ok = pv && ch < CPY && cd < g.Cd;
+      yreg[i] = __builtin_amdgcn_raw_buffer_load_b128(dyR, ok ? (unsigned)((pp * g.Cd + cd) * ES) : OOB, 0, 0);
+    }
+    const int n = fdiv(pp, HWm, rcp_hw), rem = pp - n * HWm;
+    const int hm = fdiv(rem, g.Wm, rcp_w), wq = rem - hm * g.Wm;
+    const int hs0 = pv ? hm * g.sh + g.oh : -(1 << 21), ws0 = wq * g.sw + g.ow;
+    const int base = (((n * g.Hs + hs0) * g.Ws + ws0) * g.Cs) * ES;
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const bool ok = (unsigned)(hs0 + xdh[i]) < (unsigned)g.Hs && (unsigned)(ws0 + xdw[i]) < (unsigned)g.Ws;
+      xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srcR, ok ? (unsigned)(base + xdelta[i]) : OOB, 0, 0);
+    }
   };
-  auto store_tile = [&](int buf) __attribute__((always_inline)) {
-    *reinterpret_cast<uint4*>(&Ys[buf][lrow * PITCH + lchunk * E]) = yreg;
-    *reinterpret_cast<uint4*>(&Xs[buf][lrow * PITCH + lchunk * E]) = xreg;
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NYI; ++i) {
+      const int ch = tq + TPR * i;
+      if (ch < CPY) *reinterpret_cast<u32x4*>(Ys + lrow * PY + ch * E) = yreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int ch = tq + TPR * i;
+      if (ch < CPX) *reinterpret_cast<u32x4*>(Xs + lrow * PX + ch * E) = xreg[i];
+    }
   };
 
-  f32x4 acc[2][2];
+  f32x4 acc[RT][CTW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < CTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int li = lane & 15, gq = lane >> 4;
   const int nk = (p_end - p_begin + BKP - 1) / BKP;
-  if (nk > 0) { load_tile(p_begin); store_tile(0); }
-  __syncthreads();
+  if (nk > 0) load_tile(p_begin);
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(p_begin + (kt + 1) * BKP);
-    const T* Yb = Ys[cur];
-    const T* Xb = Xs[cur];
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nk) load_tile(p_begin + (kt + 1) * BKP);       // in flight while this tile is consumed
     if constexpr (sizeof(T) == 2) {
-      // group gq reads rows 8gq+q (+4), lane 4q+p supplies row q, columns 4p..4p+3
-      const int q = li >> 2, pcol = (li & 3) * 4;
-      bf16x8 af[2], bf[2];
+      typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+      const int q = li >> 2, pcol = (li & 3) * 4;                // lane 4q+p supplies row q, columns 4p..4p+3 of its 16-lane group
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int cbase = wr * 32 + i * 16 + pcol;
-        typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Yb + (8 * gq + q) * PITCH + cbase));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Yb + (8 * gq + 4 + q) * PITCH + cbase));
-        af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const int xbase = wc * 32 + i * 16 + pcol;
-        const bf16x4 xl = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xb + (8 * gq + q) * PITCH + xbase));
-        const bf16x4 xh = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xb + (8 * gq + 4 + q) * PITCH + xbase));
-        bf[i] = bf16x8{xl[0], xl[1], xl[2], xl[3], xh[0], xh[1], xh[2], xh[3]};
-      }
+      for (int ks = 0; ks < BKP / 32; ++ks) {
+        const int r_lo = ks * 32 + 8 * gq + q;
+        bf16x8 af[RT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int s = 0; s < BKP / 4; ++s) {
-        float af[2], bf[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          af[i] = Yb[(4 * s + gq) * PITCH + wr * 32 + i * 16 + li];
-          bf[i] = Xb[(4 * s + gq) * PITCH + wc * 32 + i * 16 + li];
+        for (int i = 0; i < RT; ++i) {
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Ys + r_lo * PY + i * 16 + pcol));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Ys + (r_lo + 4) * PY + i * 16 + pcol));
+          af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < CTW; ++j) {
+          const int ct = wave + 4 * j;                          // uniform per wave
+          if (ct < NCT) {
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xs + r_lo * PX + ct * 16 + pcol));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xs + (r_lo + 4) * PX + ct * 16 + pcol));
+            const bf16x8 bf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < RT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s4 = 0; s4 < BKP / 4; ++s4) {
+        float af[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) af[i] = Ys[(4 * s4 + gq) * PY + i * 16 + li];
+#pragma unroll
+        for (int j = 0; j < CTW; ++j) {
+          const int ct = wave + 4 * j;
+          if (ct < NCT) {
+            const float bf = Xs[(4 * s4 + gq) * PX + ct * 16 + li];
+#pragma unroll
+            for (int i = 0; i < RT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][j], 0, 0, 0);
+          }
+        }
       }
     }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
-    __syncthreads();
+    __syncthreads();                                             // operand reads done before the next store
   }
 
   // D[row = cd (gq*4+r)][col = column li]
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = col0 + wc * 32 + j * 16 + li;
-    if (col >= ncols) continue;
+  for (int j = 0; j < CTW; ++j) {
+    const int ct = wave + 4 * j;
+    const int col = col0 + ct * 16 + li;
+    if (ct >= NCT || col >= ncols) continue;
     const int t = col / g.Cs, c = col - t * g.Cs;
     int a, b, wtc;
     decode_tap(taptab[t], a, b, wtc);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int cd = cd0 + wr * 32 + i * 16 + gq * 4 + r;
+        const int cd = cd0 + i * 16 + gq * 4 + r;
         if (cd < g.Cd) unsafeAtomicAdd(dw + ((size_t)cd * g.wtaps + wtc) * g.Cs + c, acc[i][j][r]);
       }
   }
+}
+
+template <typename T, int BMW, int NCT>
+int launch_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t& g, int P, hipStream_t s) {
+  constexpr int BKP = WgradCfg<T>::BKP, PAD = WgradCfg<T>::PAD;
+  constexpr int LDS = (int)sizeof(T) * BKP * ((BMW + PAD) + (NCT * 16 + PAD)) + 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    AST_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<T, BMW, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const int gx = (g.Cd + BMW - 1) / BMW, gy = (g.ntaps * g.Cs + NCT * 16 - 1) / (NCT * 16);
+  const int tiles = gx * gy;
+  int nsplit = std::max(1, std::min((P + 4 * BKP - 1) / (4 * BKP), (768 + tiles - 1) / tiles));
+  int pps = (P + nsplit - 1) / nsplit;
+  pps = (pps + BKP - 1) / BKP * BKP;
+  nsplit = (P + pps - 1) / pps;
+  const unsigned dy_bytes = (unsigned)((size_t)P * g.Cd * sizeof(T));
+  const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
+  hipLaunchKernelGGL((wgrad_kernel<T, BMW, NCT>), dim3(gx, gy, nsplit), dim3(256), LDS, s, (const T*)dy, (const T*)src, dw, g, P, pps,
+                     dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm);
+  AST_CHECK_LAUNCH();
+  return 0;
 }
 
 struct IgemmPlan { int bm, bn, kch, nsplit, kt_per_split, depth; };
@@ -541,17 +598,20 @@ extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_g
   const ast_gather_t g = *gp;
   if (g.ntaps == 0) return 0;
   const int P = g.N * g.Hm * g.Wm;
-  const int tiles = ((g.Cd + 63) / 64) * ((g.ntaps * g.Cs + 63) / 64);
-  const int bkp = dtype == AST_BF16 ? 32 : 16;
-  int nsplit = max(1, min((P + 8 * bkp - 1) / (8 * bkp), (1024 + tiles - 1) / tiles));
-  int pps = (P + nsplit - 1) / nsplit;
-  pps = (pps + bkp - 1) / bkp * bkp;
-  nsplit = (P + pps - 1) / pps;
-  dim3 grid((g.Cd + 63) / 64, (g.ntaps * g.Cs + 63) / 64, nsplit);
+  if ((long)P * g.Cd * 4 >= (1L << 31)) AST_FAIL("ast_wgrad: dy exceeds the 2 GiB buffer-addressing range");
   hipStream_t s = (hipStream_t)stream;
+  const int nct_all = (g.ntaps * g.Cs + 15) / 16;          // column tiles of the whole (tap, channel) space
+  const int bmw = g.Cd > 32 ? 64 : (g.Cd > 16 ? 32 : 16);
+  // all columns in one workgroup when the accumulators fit (<= 20 tiles x BMW/16 row tiles <= 20 per wave)
+  int nct;
+  if (bmw == 64) nct = nct_all <= 8 ? (nct_all <= 4 ? 4 : 8) : 12;
+  else nct = nct_all <= 4 ? 4 : (nct_all <= 8 ? 8 : (nct_all <= 12 ? 12 : 20));
+#define AST_WG(B_, N_) return launch_wgrad<T, B_, N_>(dy, src, dw, g, P, s)
   AST_DISPATCH_T(dtype, {
-    hipLaunchKernelGGL((wgrad_kernel<T>), grid, dim3(256), 0, s, (const T*)dy, (const T*)src, dw, g, P, pps);
+    if (bmw == 64) { if (nct == 4) AST_WG(64, 4); if (nct == 8) AST_WG(64, 8); AST_WG(64, 12); }
+    if (bmw == 32) { if (nct == 4) AST_WG(32, 4); if (nct == 8) AST_WG(32, 8); if (nct == 12) AST_WG(32, 12); AST_WG(32, 20); }
+    if (nct == 4) AST_WG(16, 4); if (nct == 8) AST_WG(16, 8); if (nct == 12) AST_WG(16, 12); AST_WG(16, 20);
   });
-  AST_CHECK_LAUNCH();
+#undef AST_WG
   return 0;
 }
