@@ -70,6 +70,8 @@ _SIGS = {
     "ast_infonce": ([vp, vp, i32, i32, f32, vp, vp, vp, vp], i32),
     "ast_margin": ([vp, i32, i32, f32, vp, vp, vp], i32),
     "ast_hsic": ([vp, vp, i32, i32, vp, vp, vp, vp, vp], i32),
+    "ast_crosscov": ([vp, vp, i32, i32, vp, vp, vp, vp, vp], i32),
+    "ast_istft": ([vp, i32, i32, vp, vp, vp], i32),
     "ast_cross_entropy": ([vp, vp, i32, i32, vp, vp, vp], i32),
     "ast_softmax_entropy": ([vp, i32, i32, vp, vp, vp], i32),
     "ast_scale": ([vp, vp, f32, vp, i64, i32, vp], i32),

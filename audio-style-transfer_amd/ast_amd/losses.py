@@ -42,7 +42,7 @@ def adversarial_loss(style_emb, class_emb, content_emb, discriminator, labels, c
 
 
 def disentanglement_loss(style_emb: torch.Tensor, content_emb: torch.Tensor, use_hsic: bool = True, weight=20.0) -> torch.Tensor:
-    """losses.py:138-191 (HSIC with the median heuristic; `weight` is unused there too)."""
+    """losses.py:138-191 (HSIC with the median heuristic, or the cross-covariance penalty; `weight` is unused there too)."""
     if not use_hsic:
-        raise NotImplementedError("cross-covariance variant (use_hsic=False) is not built yet: SURVEY 8(f)")
+        return ops.CrossCovFn.apply(style_emb, content_emb)
     return ops.HSICFn.apply(style_emb, content_emb)

@@ -738,6 +738,24 @@ class HSICFn(torch.autograd.Function):
         return _scaled(ds, g), _scaled(dc, g)
 
 
+class CrossCovFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s, c):
+        s, c = s.contiguous(), c.contiguous()
+        B, D = s.shape
+        loss = torch.empty(1, dtype=torch.float32, device=s.device)
+        ds, dc = torch.empty_like(s), torch.empty_like(c)
+        ws = torch.empty(2 * D + 2 * B * B, dtype=torch.float32, device=s.device)
+        check(lib().ast_crosscov(ptr(s), ptr(c), B, D, ptr(loss), ptr(ds), ptr(dc), ptr(ws), stream()), "ast_crosscov")
+        ctx.save_for_backward(ds, dc)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        ds, dc = ctx.saved_tensors
+        return _scaled(ds, g), _scaled(dc, g)
+
+
 class CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target32):

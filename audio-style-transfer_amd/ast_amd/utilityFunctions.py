@@ -2,8 +2,8 @@
 
 get_STFT runs the LDS-staged radix-4 FFT kernel; get_overlap_windows /
 sections2spectrogram / concat_stft_cqt are index plumbing on device tensors.
-get_CQT / inverse_CQT (librosa arithmetic, parity unpinned) and load_audio
-(torchaudio decode) are not provided in this round.
+inverse_STFT runs an inverse-FFT + overlap-add kernel pair.  get_CQT / inverse_CQT (librosa arithmetic,
+parity unpinned) and load_audio (torchaudio decode) are not provided in this round.
 """
 from __future__ import annotations
 
@@ -95,6 +95,18 @@ def concat_stft_cqt(stft, cqt):
     if stft.shape[0] != cqt.shape[0] or stft.shape[1] != cqt.shape[1]:
         raise ValueError(f"Channel/Time mismatch: stft {stft.shape[:2]} vs cqt {cqt.shape[:2]}")
     return torch.cat([stft, cqt], dim=2)
+
+
+def inverse_STFT(stft_tensor, n_fft=1024, hop_length=256):
+    """utilityFunctions.py:62-82: (2, T, 513) -> waveform (256*(T-1),) via the HIP inverse-FFT + overlap-add kernels."""
+    if n_fft != 1024 or hop_length != 256:
+        raise NotImplementedError("the HIP front-end is built for n_fft=1024, hop=256 (the reference's only configuration)")
+    spec = stft_tensor.float().contiguous()
+    T = spec.shape[1]
+    frames = torch.empty((T, 1024), dtype=torch.float32, device=spec.device)
+    wave = torch.empty(256 * (T - 1), dtype=torch.float32, device=spec.device)
+    check(lib().ast_istft(ptr(spec), 1, T, ptr(frames), ptr(wave), stream()), "ast_istft")
+    return wave
 
 
 def get_CQT(*a, **k):

@@ -64,7 +64,83 @@ __global__ __launch_bounds__(256) void stft_sections_kernel(const float* __restr
     xi[f] = (z.y - mean[NBIN + f]) / (stdv[NBIN + f] + 1e-8f);
   }
 }
+// ---- inverse STFT (utilityFunctions.py:62-82, torch.istft defaults) -------------------
+// frame kernel: Hermitian extension of the one-sided bins, inverse 1024-point FFT (same Stockham
+// network on the conjugated spectrum), periodic Hann window -> frames[t][1024].
+__global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restrict__ spec, int T, float* __restrict__ frames) {
+  __shared__ float2 buf[2][NFFT];
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* re = spec + ((size_t)b * 2 + 0) * T * NBIN + (size_t)t * NBIN;
+  const float* im = spec + ((size_t)b * 2 + 1) * T * NBIN + (size_t)t * NBIN;
+#pragma unroll
+  for (int k4 = 0; k4 < 4; ++k4) {
+    const int k = tid + 256 * k4;
+    float xr, xi;
+    if (k <= NFFT / 2) { xr = re[k]; xi = (k == 0 || k == NFFT / 2) ? 0.f : im[k]; }     // c2r ignores imag of DC / Nyquist
+    else { xr = re[NFFT - k]; xi = -im[NFFT - k]; }
+    buf[0][k] = make_float2(xr, -xi);                  // conj(X): x = conj(FFT(conj(X))) / N
+  }
+  __syncthreads();
+  int cur = 0;
+#pragma unroll
+  for (int p = 1; p < NFFT; p *= 4) {
+    const int k = tid & (p - 1);
+    const int j = ((tid - k) << 2) + k;
+    const float alpha = -(float)k / (2.f * p);
+    float s1, c1, s2, c2, s3, c3;
+    sincospif(alpha, &s1, &c1); sincospif(2.f * alpha, &s2, &c2); sincospif(3.f * alpha, &s3, &c3);
+    const float2 a0 = buf[cur][tid], a1 = buf[cur][tid + 256], a2 = buf[cur][tid + 512], a3 = buf[cur][tid + 768];
+    const float2 u0 = a0;
+    const float2 u1 = make_float2(a1.x * c1 - a1.y * s1, a1.x * s1 + a1.y * c1);
+    const float2 u2 = make_float2(a2.x * c2 - a2.y * s2, a2.x * s2 + a2.y * c2);
+    const float2 u3 = make_float2(a3.x * c3 - a3.y * s3, a3.x * s3 + a3.y * c3);
+    const float2 v0 = make_float2(u0.x + u2.x, u0.y + u2.y), v1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+    const float2 v2 = make_float2(u1.x + u3.x, u1.y + u3.y);
+    const float2 d = make_float2(u1.x - u3.x, u1.y - u3.y);
+    const float2 v3 = make_float2(d.y, -d.x);
+    buf[cur ^ 1][j] = make_float2(v0.x + v2.x, v0.y + v2.y);
+    buf[cur ^ 1][j + p] = make_float2(v1.x + v3.x, v1.y + v3.y);
+    buf[cur ^ 1][j + 2 * p] = make_float2(v0.x - v2.x, v0.y - v2.y);
+    buf[cur ^ 1][j + 3 * p] = make_float2(v1.x - v3.x, v1.y - v3.y);
+    cur ^= 1;
+    __syncthreads();
+  }
+  float* fr = frames + ((size_t)b * T + t) * NFFT;
+#pragma unroll
+  for (int k4 = 0; k4 < 4; ++k4) {
+    const int j = tid + 256 * k4;
+    const float hann = 0.5f - 0.5f * cospif(2.f * j / NFFT);
+    fr[j] = buf[cur][j].x * (1.f / NFFT) * hann;       // real part of conj(...) = real part
+  }
+}
+// overlap-add of the 4 frames that cover each sample, divided by the window^2 envelope, centre trimmed
+__global__ void istft_ola_kernel(const float* __restrict__ frames, int T, int nout, float* __restrict__ wave) {
+  const int b = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += gridDim.x * blockDim.x) {
+    const int j = i + NFFT / 2;                        // position in the padded signal
+    float acc = 0.f, env = 0.f;
+    const int t_hi = min(T - 1, j / HOP), t_lo = max(0, (j - NFFT + HOP) / HOP);
+    for (int t = t_lo; t <= t_hi; ++t) {
+      const int o = j - t * HOP;
+      if (o < 0 || o >= NFFT) continue;
+      const float hann = 0.5f - 0.5f * cospif(2.f * o / NFFT);
+      acc += frames[((size_t)b * T + t) * NFFT + o];
+      env += hann * hann;
+    }
+    wave[(size_t)b * nout + i] = env > 1e-11f ? acc / env : acc;
+  }
+}
 }  // namespace
+
+extern "C" int ast_istft(const float* spec, int Bc, int T, float* frames_ws, float* wave, void* stream) {
+  if (!spec || !frames_ws || !wave || Bc <= 0 || T <= 1) AST_FAIL("ast_istft: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  const int nout = HOP * (T - 1);
+  hipLaunchKernelGGL(istft_frames_kernel, dim3(T, Bc), dim3(256), 0, s, spec, T, frames_ws);
+  hipLaunchKernelGGL(istft_ola_kernel, dim3((nout + 255) / 256, Bc), dim3(256), 0, s, frames_ws, T, nout, wave);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int ast_stft_sections(const float* wave, int Bc, int nsamp, const float* mean, const float* std_, float* x, int S, int win,
                                  int step, int F_total, void* stream) {

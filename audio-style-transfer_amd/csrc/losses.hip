@@ -265,6 +265,49 @@ __global__ __launch_bounds__(1024) void hsic_kernel(const float* __restrict__ s,
   }
 }
 
+// ---- cross-covariance penalty (losses.py:146-150): ||Sc^T Cc / (B-1)||_F^2 = sum_ij <Sc_i,Sc_j><Cc_i,Cc_j> / (B-1)^2
+// ws: mean_s[D] | mean_c[D] | GS[B*B] | GC[B*B]
+__global__ __launch_bounds__(1024) void crosscov_kernel(const float* __restrict__ s, const float* __restrict__ c, int B, int D,
+                                                         float* __restrict__ loss, float* __restrict__ ds, float* __restrict__ dc,
+                                                         float* __restrict__ ws) {
+  __shared__ float red[17];
+  float* ms = ws; float* mc = ws + D; float* GS = mc + D; float* GC = GS + (size_t)B * B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  for (int d = tid; d < D; d += blockDim.x) {
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < B; ++i) { a += s[(size_t)i * D + d]; b += c[(size_t)i * D + d]; }
+    ms[d] = a / B; mc[d] = b / B;
+  }
+  __syncthreads();
+  for (int p = wave; p < B * B; p += nw) {
+    const int i = p / B, j = p % B;
+    float a = 0.f, b = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      a += (s[(size_t)i * D + d] - ms[d]) * (s[(size_t)j * D + d] - ms[d]);
+      b += (c[(size_t)i * D + d] - mc[d]) * (c[(size_t)j * D + d] - mc[d]);
+    }
+    a = wave_sum(a); b = wave_sum(b);
+    if (lane == 0) { GS[p] = a; GC[p] = b; }
+  }
+  __syncthreads();
+  const float nrm = 1.f / ((float)(B - 1) * (B - 1));
+  float part = 0.f;
+  for (int p = tid; p < B * B; p += blockDim.x) part += GS[p] * GC[p];
+  part = block_sum(part, red) * nrm;
+  if (tid == 0) loss[0] = part;
+  if (!ds || !dc) return;
+  // d/dS_i = 2 nrm sum_j GC_ij Sc_j (centring adds nothing: columns of GC sum to 0), same for C with GS
+  for (int idx = tid; idx < B * D; idx += blockDim.x) {
+    const int i = idx / D, d = idx % D;
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < B; ++j) {
+      a += GC[i * B + j] * (s[(size_t)j * D + d] - ms[d]);
+      b += GS[i * B + j] * (c[(size_t)j * D + d] - mc[d]);
+    }
+    ds[idx] = 2.f * nrm * a; dc[idx] = 2.f * nrm * b;
+  }
+}
+
 __global__ void cross_entropy_kernel(const float* __restrict__ logits, const int* __restrict__ target, int R, int C, float* __restrict__ loss,
                                      float* __restrict__ dl) {
   __shared__ float red[17];
@@ -346,6 +389,12 @@ extern "C" int ast_margin(const float* cls, int C, int D, float margin, float* l
 extern "C" int ast_hsic(const float* s, const float* c, int B, int D, float* loss, float* ds, float* dc, float* ws, void* stream) {
   if (!s || !c || !loss || !ws || B < 2 || B > 128) AST_FAIL("ast_hsic: bad args (2<=B<=128)");
   hipLaunchKernelGGL(hsic_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, s, c, B, D, loss, ds, dc, ws);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int ast_crosscov(const float* s, const float* c, int B, int D, float* loss, float* ds, float* dc, float* ws, void* stream) {
+  if (!s || !c || !loss || !ws || B < 2 || B > 256) AST_FAIL("ast_crosscov: bad args (2<=B<=256)");
+  hipLaunchKernelGGL(crosscov_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, s, c, B, D, loss, ds, dc, ws);
   AST_CHECK_LAUNCH();
   return 0;
 }

@@ -198,6 +198,8 @@ int ast_infonce(const float* emb, const int32_t* labels, int B, int D, float tem
 int ast_margin(const float* cls, int C, int D, float margin, float* loss, float* dcls, void* stream);
 int ast_hsic(const float* s, const float* c, int B, int D, float* loss, float* ds, float* dc,
              float* ws /* 6*B*B + 2*B + 8 floats */, void* stream);
+/* cross-covariance variant of disentanglement_loss (losses.py:146-150); ws: 2*D + 2*B*B floats */
+int ast_crosscov(const float* s, const float* c, int B, int D, float* loss, float* ds, float* dc, float* ws, void* stream);
 /* mean cross entropy over rows of logits (R,C); dlogits optional */
 int ast_cross_entropy(const float* logits, const int32_t* target, int R, int C, float* loss, float* dlogits, void* stream);
 /* mean entropy with log(p+1e-8) (losses.py:118-120) */
@@ -217,6 +219,9 @@ int ast_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
 /* wave (Bc, nsamp) f32 -> x (Bc, S, 2, 287, F_total) f32: frames of a 1024-point Hann STFT (hop 256,
  * reflect padded), z-scored with mean/std (2,513), cut into S sections of 287 frames (step 191), written
  * to bins [0,513) of the F_total-wide rows. */
+/* inverse_STFT (utilityFunctions.py:62-82; torch.istft defaults): spec (Bc,2,T,513) f32 -> wave (Bc, 256*(T-1));
+ * frames_ws: Bc*T*1024 floats of scratch. */
+int ast_istft(const float* spec, int Bc, int T, float* frames_ws, float* wave, void* stream);
 int ast_stft_sections(const float* wave, int Bc, int nsamp, const float* mean, const float* std_,
                       float* x, int S, int win, int step, int F_total, void* stream);
 

@@ -428,6 +428,40 @@ def test_stft_frontend(golden_dir):
     assert np.allclose(U.sections2spectrogram(win, 345).cpu().numpy(), g["recon_4s"], rtol=1e-6)
 
 
+def test_istft_roundtrip_and_golden(golden_dir):
+    from ast_amd import utilityFunctions as U
+    g = np.load(os.path.join(golden_dir, "frontend.npz"))
+    w = FO.synth_waveform(0, "piano", 4.0)
+    spec = torch.from_numpy(FO.stft(w)).to(DEV)
+    rec = U.inverse_STFT(spec)
+    assert rec.shape[0] == int(g["istft_len"]) == 256 * 344
+    assert np.abs(rec[::97].cpu().numpy() - g["istft_piano0_sub"]).max() < 2e-5       # the reference's torch.istft
+    assert np.abs(rec.cpu().numpy() - FO.istft(FO.stft(w))).max() < 2e-5               # the oracle
+    assert np.abs(rec.cpu().numpy() - w[:rec.shape[0]]).max() < 2e-5                   # STFT -> iSTFT round trip
+    # full HIP round trip: HIP STFT -> HIP iSTFT
+    rt = U.inverse_STFT(U.get_STFT(torch.from_numpy(w).to(DEV)))
+    assert np.abs(rt.cpu().numpy() - w[:rt.shape[0]]).max() < 2e-5
+
+
+@pytest.mark.parametrize("B", [2, 8, 16])
+def test_crosscov_loss(golden_dir, B):
+    g = np.load(os.path.join(golden_dir, "losses.npz"))
+    rng = np.random.default_rng([77, B])
+    style = torch.tensor(rng.standard_normal((B, 256)).astype(np.float32))
+    content = torch.tensor(rng.standard_normal((B, 3, 256)).astype(np.float32)) if B in (8, 16) else torch.randn(B, 3, 256)
+    sr, cr = style.clone().requires_grad_(True), content.clone().requires_grad_(True)
+    sh, ch = style.to(DEV).requires_grad_(True), content.to(DEV).requires_grad_(True)
+    lr = O.disentanglement_loss(sr, cr.mean(1), use_hsic=False)
+    lg = ast_amd.disentanglement_loss(sh, ch.mean(1), use_hsic=False)
+    assert math.isclose(float(lg), float(lr), rel_tol=2e-4, abs_tol=1e-7)
+    if B in (8, 16):
+        assert math.isclose(float(lg), float(g[f"B{B}_crosscov"]), rel_tol=2e-4)
+    lr.backward(); lg.backward()
+    assert rel_err(sh.grad, sr.grad) < 1e-3 and rel_err(ch.grad, cr.grad) < 1e-3
+    if B in (8, 16):
+        assert rel_err(sh.grad, torch.tensor(g[f"B{B}_crosscov_dstyle"])) < 1e-3
+
+
 def test_optimizer_kernels():
     from ast_amd._lib import lib, check, ptr, stream
     torch.manual_seed(10)
