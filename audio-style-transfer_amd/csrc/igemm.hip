@@ -461,7 +461,8 @@ int launch_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t&
   }
   const int gx = (g.Cd + BMW - 1) / BMW, gy = (g.ntaps * g.Cs + NCT * 16 - 1) / (NCT * 16);
   const int tiles = gx * gy;
-  int nsplit = std::max(1, std::min((P + 4 * BKP - 1) / (4 * BKP), (768 + tiles - 1) / tiles));
+  const int wg_target = P >= 1500000 ? 768 : 256;       // see launch_wgrad_halo
+  int nsplit = std::max(1, std::min((P + 4 * BKP - 1) / (4 * BKP), (wg_target + tiles - 1) / tiles));
   int pps = (P + nsplit - 1) / nsplit;
   pps = (pps + BKP - 1) / BKP * BKP;
   nsplit = (P + pps - 1) / pps;
@@ -469,6 +470,238 @@ int launch_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t&
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
   hipLaunchKernelGGL((wgrad_kernel<T, BMW, NCT>), dim3(gx, gy, nsplit), dim3(256), LDS, s, (const T*)dy, (const T*)src, dw, g, P, pps,
                      dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Halo-tile weight gradient for the small-channel layers (Cd <= 64, all (tap, channel) columns
+// <= 320 per workgroup).  The gathered kernel above fetches every source pixel once per tap
+// (9x for 3x3) and spends ~8 VALU per 16-byte chunk on addressing: ~1.5 VALU cycles per MFMA
+// cycle on these layers.  Here a workgroup walks 8x16-pixel tiles of dy: per tile it stages dy
+// (128 x Cd) and the source patch (tile + halo, each pixel ONCE) in LDS, and every tap's B operand
+// is a transposed read of the patch at a shifted address.  Accumulators stay in registers across
+// all tiles of the workgroup; one atomic flush at the end.
+// ---------------------------------------------------------------------------
+constexpr int WH_TH = 8, WH_TW = 16, WH_MAXPL = 10;
+struct WHaloPlan { int PH, PW, dhmin, dwmin, tiles_h, tiles_w, ntiles, lds; };
+
+template <typename T, int BMW, int NCT>
+__global__ __launch_bounds__(256) void wgrad_halo_kernel(const T* __restrict__ dy, const T* __restrict__ src,
+                                                          float* __restrict__ dw, const ast_gather_t g, const WHaloPlan hp,
+                                                          const unsigned dy_bytes, const unsigned src_bytes) {
+  constexpr int E = 16 / sizeof(T), ES = sizeof(T);
+  constexpr int MT = WH_TH * WH_TW;                 // 128 pixels per tile
+  constexpr int PADY = sizeof(T) == 2 ? 8 : 16;
+  constexpr int PY = BMW + PADY;                    // dy tile pitch (elements)
+  constexpr int CPY = BMW / E;                      // dy chunks per pixel
+  constexpr int NYI = (MT * CPY + 255) / 256;
+  constexpr int RT = BMW / 16, CTW = (NCT + 3) / 4;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
+  T* Ys = reinterpret_cast<T*>(wl);
+  T* Xp = Ys + MT * PY;                             // patch [PH*PW][Cs + pad]
+  const int PPX = g.Cs + (sizeof(T) == 2 ? 8 : 4);  // patch pixel pitch (elements): breaks the power-of-two stride
+  int* taptab = reinterpret_cast<int*>(Xp + hp.PH * hp.PW * PPX);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cd0 = blockIdx.x * BMW, col0 = blockIdx.y * NCT * 16;
+  const int ncols = g.ntaps * g.Cs;
+  const int UP = g.Cs / E;                          // 16-byte chunks per patch pixel
+  const int PH = hp.PH, PW = hp.PW;
+  const __amdgpu_buffer_rsrc_t dyR = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srcR = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, src_bytes, 0x00020000);
+#pragma unroll
+  for (int t = 0; t < AST_MAX_TAPS; ++t)
+    if (tid == t) {
+      int dh, dwv, wt;
+      decode_tap(g.tap[t], dh, dwv, wt);
+      taptab[t] = ((dh - hp.dhmin) * PW + (dwv - hp.dwmin)) * PPX;   // patch element offset of the tap
+      taptab[16 + t] = wt;
+    }
+  __syncthreads();
+
+  // ---- loader descriptors: patch slots (py, px, part) and dy slots (pixel, chunk)
+  int ppy[WH_MAXPL], ppx[WH_MAXPL], pgo[WH_MAXPL], plo[WH_MAXPL];
+  const int npatch = PH * PW * UP;
+#pragma unroll
+  for (int i = 0; i < WH_MAXPL; ++i) {
+    const int idx = tid + 256 * i;
+    ppy[i] = -(1 << 20); ppx[i] = 0; pgo[i] = 0; plo[i] = -1;
+    if (idx < npatch) {
+      const int pix = idx / UP, part = idx - pix * UP;
+      ppy[i] = pix / PW; ppx[i] = pix - ppy[i] * PW;
+      pgo[i] = ((ppy[i] * g.Ws + ppx[i]) * g.Cs + part * E) * ES;
+      plo[i] = pix * PPX + part * E;
+    }
+  }
+  int ypix[NYI], ych[NYI];
+#pragma unroll
+  for (int i = 0; i < NYI; ++i) {
+    const int idx = tid + 256 * i;
+    ypix[i] = idx < MT * CPY ? idx / CPY : -1;
+    ych[i] = idx < MT * CPY ? idx % CPY : 0;
+  }
+  // ---- per-lane operand offsets
+  const int li = lane & 15, gq = lane >> 4;
+  int coloff[CTW];                                  // patch element offset of this lane's column (tap, channel) per column tile
+  bool colok[CTW];
+#pragma unroll
+  for (int j = 0; j < CTW; ++j) {
+    const int ct = wave + 4 * j;
+    const int col = col0 + ct * 16 + (sizeof(T) == 2 ? (li & 3) * 4 : li);
+    colok[j] = ct < NCT && col < ncols;
+    const int t = colok[j] ? col / g.Cs : 0;
+    coloff[j] = taptab[t] + (colok[j] ? col - t * g.Cs : 0);
+  }
+
+  f32x4 acc[RT][CTW];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 preg[WH_MAXPL], yreg[NYI];
+  auto load_tile = [&](int tile) __attribute__((always_inline)) {
+    const int per_img = hp.tiles_h * hp.tiles_w;
+    const int n = tile / per_img, r = tile - n * per_img;
+    const int th = r / hp.tiles_w, tw = r - th * hp.tiles_w;
+    const int hm0 = th * WH_TH, wm0 = tw * WH_TW;
+    const int hs_org = hm0 * g.sh + g.oh + hp.dhmin, ws_org = wm0 * g.sw + g.ow + hp.dwmin;
+    const int base = (((n * g.Hs + hs_org) * g.Ws + ws_org) * g.Cs) * ES;
+#pragma unroll
+    for (int i = 0; i < WH_MAXPL; ++i) {
+      const bool ok = plo[i] >= 0 && (unsigned)(hs_org + ppy[i]) < (unsigned)g.Hs && (unsigned)(ws_org + ppx[i]) < (unsigned)g.Ws;
+      preg[i] = __builtin_amdgcn_raw_buffer_load_b128(srcR, ok ? (unsigned)(base + pgo[i]) : OOB, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NYI; ++i) {
+      const int ty = ypix[i] >> 4, tx = ypix[i] & 15;
+      const int hm = hm0 + ty, wq = wm0 + tx;
+      const int cd = cd0 + ych[i] * E;
+      const bool ok = ypix[i] >= 0 && hm < g.Hm && wq < g.Wm && cd < g.Cd;
+      yreg[i] = __builtin_amdgcn_raw_buffer_load_b128(dyR, ok ? (unsigned)((((n * g.Hm + hm) * g.Wm + wq) * g.Cd + cd) * ES) : OOB, 0, 0);
+    }
+  };
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WH_MAXPL; ++i)
+      if (plo[i] >= 0) *reinterpret_cast<u32x4*>(Xp + plo[i]) = preg[i];
+#pragma unroll
+    for (int i = 0; i < NYI; ++i)
+      if (ypix[i] >= 0) *reinterpret_cast<u32x4*>(Ys + ypix[i] * PY + ych[i] * E) = yreg[i];
+  };
+
+  int tile = blockIdx.z;
+  if (tile < hp.ntiles) load_tile(tile);
+  for (; tile < hp.ntiles; tile += gridDim.z) {
+    store_tile();
+    __syncthreads();
+    if (tile + (int)gridDim.z < hp.ntiles) load_tile(tile + gridDim.z);     // next tile in flight during the MFMAs
+    if constexpr (sizeof(T) == 2) {
+      typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+      const int q = li >> 2, pcol = (li & 3) * 4;
+#pragma unroll
+      for (int ks = 0; ks < MT / 32; ++ks) {
+        // rows (pixels) of this lane's two 4-row blocks: p = 32 ks + 8 gq + q (+4); tile row = p >> 4, column = p & 15
+        const int p_lo = ks * 32 + 8 * gq + q, p_hi = p_lo + 4;
+        const int x_lo = (((p_lo >> 4) * g.sh) * PW + (p_lo & 15) * g.sw) * PPX;
+        const int x_hi = (((p_hi >> 4) * g.sh) * PW + (p_hi & 15) * g.sw) * PPX;
+        bf16x8 af[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Ys + p_lo * PY + i * 16 + pcol));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Ys + p_hi * PY + i * 16 + pcol));
+          af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int j = 0; j < CTW; ++j) {
+          if (wave + 4 * j < NCT) {                                         // uniform per wave; masked columns read a valid address
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xp + x_lo + coloff[j]));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xp + x_hi + coloff[j]));
+            const bf16x8 bf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int i = 0; i < RT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int s4 = 0; s4 < MT / 4; ++s4) {
+        const int p = 4 * s4 + gq;
+        const int xo = (((p >> 4) * g.sh) * PW + (p & 15) * g.sw) * PPX;
+        float af[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) af[i] = Ys[p * PY + i * 16 + li];
+#pragma unroll
+        for (int j = 0; j < CTW; ++j) {
+          if (wave + 4 * j < NCT) {
+            const float bf = colok[j] ? Xp[xo + coloff[j]] : 0.f;
+#pragma unroll
+            for (int i = 0; i < RT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // D[row = cd (gq*4+r)][col = column li]
+#pragma unroll
+  for (int j = 0; j < CTW; ++j) {
+    const int ct = wave + 4 * j;
+    const int col = col0 + ct * 16 + li;
+    if (ct >= NCT || col >= ncols) continue;
+    const int t = col / g.Cs, c = col - t * g.Cs;
+    const int wtc = taptab[16 + t];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cd = cd0 + i * 16 + gq * 4 + r;
+        if (cd < g.Cd) unsafeAtomicAdd(dw + ((size_t)cd * g.wtaps + wtc) * g.Cs + c, acc[i][j][r]);
+      }
+  }
+}
+
+bool plan_wgrad_halo(const ast_gather_t& g, int dtype, int nct, int bmw, WHaloPlan& hp) {
+  if (g.ntaps < 2 || g.Cd > 32) return false;          // measured: wins for <= 32 output channels, loses at 64
+  const int E = dtype == AST_BF16 ? 8 : 4, ES = dtype == AST_BF16 ? 2 : 4;
+  int dhmin = 64, dhmax = -64, dwmin = 64, dwmax = -64;
+  for (int t = 0; t < g.ntaps; ++t) {
+    const int dh = (g.tap[t] & 255) - 64, dw = ((g.tap[t] >> 8) & 255) - 64;
+    dhmin = std::min(dhmin, dh); dhmax = std::max(dhmax, dh); dwmin = std::min(dwmin, dw); dwmax = std::max(dwmax, dw);
+  }
+  hp.dhmin = dhmin; hp.dwmin = dwmin;
+  hp.PH = (WH_TH - 1) * g.sh + (dhmax - dhmin) + 1;
+  hp.PW = (WH_TW - 1) * g.sw + (dwmax - dwmin) + 1;
+  if (hp.PH * hp.PW * (g.Cs / E) > 256 * WH_MAXPL) return false;
+  hp.tiles_h = (g.Hm + WH_TH - 1) / WH_TH; hp.tiles_w = (g.Wm + WH_TW - 1) / WH_TW;
+  hp.ntiles = g.N * hp.tiles_h * hp.tiles_w;
+  const int ppx = g.Cs + (ES == 2 ? 8 : 4), pady = ES == 2 ? 8 : 16;
+  hp.lds = ES * (WH_TH * WH_TW * (bmw + pady) + hp.PH * hp.PW * ppx) + 160;
+  if (hp.lds > 96 * 1024) return false;
+  // tile quantisation: skip when the 8x16 tiling wastes most of the work (tiny images go to the gathered kernel)
+  const double eff = (double)g.Hm * g.Wm / ((double)hp.tiles_h * hp.tiles_w * WH_TH * WH_TW);
+  return eff >= 0.6 && hp.ntiles >= 256;
+}
+
+template <typename T, int BMW, int NCT>
+int launch_wgrad_halo(const void* dy, const void* src, float* dw, const ast_gather_t& g, const WHaloPlan& hp, hipStream_t s) {
+  static int attr_lds = 0;
+  if (hp.lds > attr_lds) {
+    AST_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<T, BMW, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_lds = 96 * 1024;
+  }
+  const int gx = (g.Cd + BMW - 1) / BMW, gy = (g.ntaps * g.Cs + NCT * 16 - 1) / (NCT * 16);
+  // every workgroup adds its whole dW tile into the same few KB: fewer workgroups = less same-address atomic
+  // contention; only the largest pixel counts need more than one workgroup per CU (sweep in profiles/r01)
+  const int wg_target = (long)g.N * g.Hm * g.Wm >= 1500000 ? 768 : 256;
+  const int gz = std::max(1, std::min(hp.ntiles, wg_target / (gx * gy)));
+  const unsigned dy_bytes = (unsigned)((size_t)g.N * g.Hm * g.Wm * g.Cd * sizeof(T));
+  const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
+  hipLaunchKernelGGL((wgrad_halo_kernel<T, BMW, NCT>), dim3(gx, gy, gz), dim3(256), hp.lds, s, (const T*)dy, (const T*)src, dw, g, hp,
+                     dy_bytes, src_bytes);
   AST_CHECK_LAUNCH();
   return 0;
 }
@@ -606,7 +839,10 @@ extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_g
   int nct;
   if (bmw == 64) nct = nct_all <= 8 ? (nct_all <= 4 ? 4 : 8) : 12;
   else nct = nct_all <= 4 ? 4 : (nct_all <= 8 ? 8 : (nct_all <= 12 ? 12 : 20));
-#define AST_WG(B_, N_) return launch_wgrad<T, B_, N_>(dy, src, dw, g, P, s)
+  WHaloPlan whp;
+  const bool halo = plan_wgrad_halo(g, dtype, nct, bmw, whp);
+#define AST_WG(B_, N_) do { if (halo) return launch_wgrad_halo<T, B_, N_>(dy, src, dw, g, whp, s); \
+                            return launch_wgrad<T, B_, N_>(dy, src, dw, g, P, s); } while (0)
   AST_DISPATCH_T(dtype, {
     if (bmw == 64) { if (nct == 4) AST_WG(64, 4); if (nct == 8) AST_WG(64, 8); AST_WG(64, 12); }
     if (bmw == 32) { if (nct == 4) AST_WG(32, 4); if (nct == 8) AST_WG(32, 8); if (nct == 12) AST_WG(32, 12); AST_WG(32, 20); }
