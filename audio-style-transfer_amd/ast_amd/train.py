@@ -126,6 +126,7 @@ class Trainer:
         self._y_emb = None
         self._carry = None
         self._parts = None
+        self._frontend = None
         self._static = None
         self.losses = {}
 
@@ -202,6 +203,7 @@ class Trainer:
 
     # The step as three segments; the data-parallel gradient all-reduces sit between them.
     def _seg_a(self, x, labels_host):
+        self._run_frontend(x)
         self._carry = self._forward_backward(x, labels_host)          # zero grads, encoders fwd, D-phase fwd+bwd
 
     def _seg_b(self, x, labels_host):
@@ -226,6 +228,19 @@ class Trainer:
         return self._parts
 
     # ------------------------------------------------------------------ public API
+    def set_frontend(self, waves, mean, std):
+        """Make the STFT front-end part of the step: every step() first runs the fused STFT + z-score +
+        sectioning kernel (utilityFunctions.py:12-37,240-263; dataloader.py:9-13) from these device-resident
+        waveforms straight into bins [0,513) of x (the collate layout of dataloader.py:123-147)."""
+        self._frontend = (waves.contiguous(), mean.contiguous(), std.contiguous())
+
+    def _run_frontend(self, x):
+        if self._frontend is None:
+            return
+        from .utilityFunctions import stft_sections
+        waves, mean, std = self._frontend
+        stft_sections(waves, mean, std, n_sections=x.shape[1], F_total=x.shape[-1], out=x)
+
     def step(self, x: torch.Tensor, labels_host: torch.Tensor):
         """x: (B,S,2,287,597) f32 on the device; labels on the HOST (balanced [0]*B/2+[1]*B/2 as
         dataloader.py:143-146 builds them).  Returns a dict of detached device scalars."""
@@ -296,6 +311,36 @@ class Trainer:
             for t, sv in zip(state, saved):
                 t.copy_(sv)
         self._graphs[key] = (graphs, static_x, outs)
+
+
+def synthetic_waveform_batch(B, seconds, device, seed=1000, sr=22050):
+    """Synthetic clips for the front-end-inclusive step: B mono waveforms (first half piano-like decaying
+    partials, second half violin-like sustained harmonics with vibrato), RMS 0.07, plus N(0,1) stand-ins for
+    the 84 z-scored CQT bins (CQT is librosa arithmetic: parity-unpinned, not built) and per-bin statistics."""
+    g = torch.Generator().manual_seed(seed)
+    n = int(round(seconds * sr))
+    t = torch.arange(n, dtype=torch.float32) / sr
+    waves = []
+    for i in range(B):
+        f0 = 110.0 * 2 ** (torch.randint(0, 36, (1,), generator=g).item() / 12)
+        y = torch.zeros(n)
+        if i < B // 2:
+            for h in range(1, 7):
+                y += torch.exp(-3.0 * h * (t % 0.5)) * torch.sin(2 * torch.pi * f0 * h * t) / h
+        else:
+            for h in range(1, 9):
+                y += torch.sin(2 * torch.pi * f0 * h * t + 0.3 * h * torch.sin(2 * torch.pi * 5.5 * t)) / h
+        y += 0.01 * torch.randn(n, generator=g)
+        waves.append(0.07 * y / y.pow(2).mean().sqrt())
+    waves = torch.stack(waves).to(device)
+    T = 1 + n // 256
+    from .utilityFunctions import section_starts
+    S = len(section_starts(T))
+    x = torch.randn((B, S, 2, 287, 597), generator=g, dtype=torch.float32).to(device)     # bins 513.. = CQT stand-in
+    mean = (0.01 * torch.randn(2, 513, generator=g)).to(device)
+    std = (0.5 + torch.rand(2, 513, generator=g)).to(device)
+    labels = torch.cat([torch.zeros(B // 2, dtype=torch.long), torch.ones(B - B // 2, dtype=torch.long)])
+    return waves, x, mean, std, labels
 
 
 def synthetic_batch(B, S, device, seed=1000):

@@ -105,6 +105,33 @@ def kernel_roofline(trainer, x, labels, dtype_name):
     return roof
 
 
+def ar_decode_bench(tr, x, labels, S, iters=10):
+    """BASELINE configs[3]: eval-mode encoders + autoregressive new_decoder generation of S sections -> STFT frames/s."""
+    import ast_amd
+    for m in (tr.style, tr.content, tr.decoder):
+        m.eval()
+    idx = labels.to(x.device)
+    def run():
+        with torch.no_grad():
+            se, ce = tr.style(x, labels)
+            co = tr.content(x)
+            return tr.decoder(co, ce[idx])
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    for m in (tr.style, tr.content, tr.decoder):
+        m.train()
+    B = x.shape[0]
+    frames = B * (191 * (S - 1) + 287)
+    return {"ms_per_batch": dt * 1e3, "stft_frames_per_s": frames / dt, "audio_seconds_per_s": B * CLIP_SECONDS / dt,
+            "note": "eager (no graph), encoders + O(S^2) decoder loop as in new_decoder.py:272-319"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +141,8 @@ def main():
     ap.add_argument("--sections", type=int, default=2, help="S=2 <=> 4 s clips")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-frontend", action="store_true", help="feed a resident model-ready x instead of running the STFT kernel each step")
+    ap.add_argument("--infer", action="store_true", help="also time the autoregressive decode (BASELINE configs[3]) and add it to the JSON")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -140,7 +169,14 @@ def main():
     from ast_amd import train
     ast_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     tr = train.Trainer(train.TrainConfig(use_graph=not args.no_graph), device=dev, rank=rank, world=world)
-    x, labels = train.synthetic_batch(args.batch, args.sections, dev, seed=1000 + rank)
+    clip_seconds = {1: 3.0, 2: CLIP_SECONDS, 3: 8.0, 4: 10.0}[args.sections]   # clip length that yields S sections
+    if args.no_frontend:
+        x, labels = train.synthetic_batch(args.batch, args.sections, dev, seed=1000 + rank)
+    else:
+        # waveforms resident in HBM; every step runs STFT + z-score + sectioning into x[..., :513] (x[..., 513:] = CQT stand-in)
+        waves, x, mean, std, labels = train.synthetic_waveform_batch(args.batch, clip_seconds, dev, seed=1000 + rank)
+        assert x.shape[1] == args.sections
+        tr.set_frontend(waves, mean, std)
 
     def barrier():
         if world > 1:
@@ -161,15 +197,18 @@ def main():
         dt = float(t)
     losses = {k: float(v) for k, v in tr.losses.items()}
     ms = dt / args.steps * 1e3
-    value = world * args.batch * CLIP_SECONDS / (dt / args.steps)
+    value = world * args.batch * clip_seconds / (dt / args.steps)
 
     out = {"metric": "audio-seconds/sec/node (train step, 4s@22.05kHz pairs)", "value": value, "unit": "audio-seconds/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": f"configs[1]: batch={args.batch} 4 s pairs per GPU (S={args.sections}, x=(B,S,2,287,597)), full train2 step: "
-                                  "encoders+decoder+discriminator, all losses, D and G phases, grad clip, Adam",
+           "config": {"workload": f"configs[1]: batch={args.batch} {clip_seconds:g} s clips per GPU (S={args.sections}, x=(B,S,2,287,597)), full train2 step: "
+                                  + ("" if args.no_frontend else "STFT front-end from resident waveforms (CQT bins synthetic), ")
+                                  + "encoders+decoder+discriminator, all losses, D and G phases, grad clip, Adam",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": not args.no_graph and world == 1},
            "losses": losses}
+    if rank == 0 and world == 1 and args.infer:
+        out["autoregressive_decode"] = ar_decode_bench(tr, x, labels, args.sections)
     if rank == 0 and world == 1:
         if not args.no_roofline:
             out["roofline"] = kernel_roofline(tr, x, labels, args.dtype)

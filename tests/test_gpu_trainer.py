@@ -48,3 +48,21 @@ def test_loss_goes_down_on_a_fixed_batch():
     for _ in range(25):
         last = float(tr.step(x, labels)["rec"])
     assert last < first, (first, last)
+
+
+def test_frontend_in_step_matches_prefilled_input():
+    """step() with the STFT front-end attached == step() on an x whose STFT bins were filled beforehand."""
+    from ast_amd import utilityFunctions as U
+    ast_amd.set_compute_dtype(torch.float32)
+    waves, x, mean, std, labels = train.synthetic_waveform_batch(2, 4.0, "cuda:0", seed=9)
+    assert x.shape == (2, 2, 2, 287, 597)
+    x_ref = x.clone()
+    U.stft_sections(waves, mean, std, n_sections=2, F_total=597, out=x_ref)
+    assert float((x_ref[..., :513] - x[..., :513]).abs().max()) > 0 and torch.equal(x_ref[..., 513:], x[..., 513:])
+    a = train.Trainer(train.TrainConfig(use_graph=False, dropout=False), seed=3)
+    ra = {k: float(v) for k, v in a.step(x_ref, labels).items()}
+    b = train.Trainer(train.TrainConfig(use_graph=True, dropout=False), seed=3)
+    b.set_frontend(waves, mean, std)
+    rb = {k: float(v) for k, v in b.step(x.clone(), labels).items()}
+    for k in ra:
+        assert math.isclose(ra[k], rb[k], rel_tol=2e-4, abs_tol=1e-6), (k, ra[k], rb[k])
