@@ -98,6 +98,14 @@ class WeightBank:
             self.max_co = max(self.max_co, Co)
             self.max_cols = max(self.max_cols, Ci * KK)
             self.max_packed = max(self.max_packed, n)
+        # 32x32-channel tiles of every weight for the LDS-tiled pack / flush kernels
+        tl = []
+        for wi, e in enumerate(self.entries):
+            for co0 in range(0, e.Cop, 32):
+                for ci0 in range(0, e.Cip, 32):
+                    tl += [wi, co0, ci0, 0]
+        self.ntiles = len(tl) // 4
+        self.d_tiles = torch.tensor(tl, dtype=torch.int32, device=dev)
         arr = (WeightDesc * len(descs))(*descs)
         dev_descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         if training:
@@ -114,8 +122,8 @@ class WeightBank:
         if self._keys.get(training) != self._signature(training):
             self._build(training)
         d = self.d_train if training else self.d_eval
-        check(lib().ast_weights_prepare_v(ptr(d), ptr(self.d_dtypes), len(self.entries), self.max_co, self.max_cols,
-                                          self.max_packed, stream()), "ast_weights_prepare_v")
+        check(lib().ast_weights_prepare_t(ptr(d), ptr(self.d_dtypes), len(self.entries), self.max_co, self.max_cols,
+                                          ptr(self.d_tiles), self.ntiles, stream()), "ast_weights_prepare_t")
 
     # ---- batched weight-gradient unpack, once per backward pass ----------------------
     def request_flush(self):
@@ -125,8 +133,8 @@ class WeightBank:
 
     def _flush(self):
         self._flush_pending = False
-        check(lib().ast_weight_grads_flush_v(ptr(self.d_train), len(self.entries), self.max_packed, stream()),
-              "ast_weight_grads_flush_v")
+        check(lib().ast_weight_grads_flush_t(ptr(self.d_train), ptr(self.d_tiles), self.ntiles, stream()),
+              "ast_weight_grads_flush_t")
 
 
 def img_dtype():

@@ -61,99 +61,6 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const ast_weight_desc_t* __
   }
 }
 
-// sigma, u, then pack W/sigma into wf [Cop][KK][Cip] and wb [Cip][KK][Cop]
-template <typename T>
-__device__ void pack_body(const ast_weight_desc_t& d, float inv_sigma) {
-  const size_t nf = (size_t)d.Cop * d.KK * d.Cip;
-  const size_t stride = (size_t)gridDim.x * 256;
-  if (d.wf) {
-    T* wf = (T*)d.wf;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nf; i += stride) {
-      const int ci = (int)(i % d.Cip);
-      const size_t t = i / d.Cip;
-      const int tap = (int)(t % d.KK), co = (int)(t / d.KK);
-      wf[i] = (T)((co < d.Co && ci < d.Ci) ? d.w[woff(d, co, ci, tap)] * inv_sigma : 0.f);
-    }
-  }
-  if (d.wb) {
-    T* wb = (T*)d.wb;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nf; i += stride) {
-      const int co = (int)(i % d.Cop);
-      const size_t t = i / d.Cop;
-      const int tap = (int)(t % d.KK), ci = (int)(t / d.KK);
-      wb[i] = (T)((co < d.Co && ci < d.Ci) ? d.w[woff(d, co, ci, tap)] * inv_sigma : 0.f);
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void sn_pack_kernel(const ast_weight_desc_t* __restrict__ descs, const int* __restrict__ dtypes) {
-  __shared__ float red[17];
-  const ast_weight_desc_t d = descs[blockIdx.y];
-  float inv_sigma = 1.f;
-  if (d.u) {
-    float sigma;
-    if (d.power_iter) {
-      float q = 0.f;
-      for (int i = threadIdx.x; i < d.Co; i += 256) q += d.scratch[i] * d.scratch[i];
-      const float nrm = sqrtf(block_sum(q, red));
-      const float inv = 1.f / fmaxf(nrm, 1e-12f);
-      sigma = nrm * nrm * inv;                      // u_new . (W v) with u_new = s / max(|s|, eps)
-      if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < d.Co; i += 256) d.u[i] = d.scratch[i] * inv;
-    } else {
-      float q = 0.f;
-      for (int i = threadIdx.x; i < d.Co; i += 256) q += d.scratch[i] * d.u[i];
-      sigma = block_sum(q, red);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) d.sigma[0] = sigma;
-    inv_sigma = 1.f / sigma;
-  }
-  __syncthreads();
-  if (d.u && blockIdx.x == 0)                       // leave t = W^T u zeroed for the next forward's atomics
-    for (int j = threadIdx.x; j < d.Ci * d.KK; j += 256) d.scratch[d.Co + j] = 0.f;
-  if (dtypes[blockIdx.y] == AST_BF16) pack_body<bf16_t>(d, inv_sigma); else pack_body<float>(d, inv_sigma);
-  if (d.dwp && d.power_iter) {                      // training forward: fresh gradient staging for this step
-    const size_t nf = (size_t)d.Cop * d.KK * d.Cip;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nf; i += (size_t)gridDim.x * 256) d.dwp[i] = 0.f;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && d.inner) d.inner[0] = 0.f;
-  }
-}
-
-// batched backward: inner[w] = <dWp, W>/sigma for spectral-normalised weights
-__global__ __launch_bounds__(256) void flush_inner_kernel(const ast_weight_desc_t* __restrict__ descs) {
-  __shared__ float red[17];
-  const ast_weight_desc_t d = descs[blockIdx.y];
-  if (!d.dwp || !d.u) return;
-  const size_t n = (size_t)d.Co * d.Ci * d.KK;
-  float q = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const int tap = (int)(i % d.KK);
-    const size_t t = i / d.KK;
-    const int ci = (int)(t % d.Ci), co = (int)(t / d.Ci);
-    const size_t pi = d.dwp_from_wb ? ((size_t)ci * d.KK + tap) * d.Cop + co : ((size_t)co * d.KK + tap) * d.Cip + ci;
-    q += d.dwp[pi] * d.w[woff(d, co, ci, tap)];
-  }
-  q = block_sum(q, red);
-  if (threadIdx.x == 0 && q != 0.f) unsafeAtomicAdd(d.inner, q / d.sigma[0]);
-}
-
-__global__ __launch_bounds__(256) void flush_unpack_kernel(const ast_weight_desc_t* __restrict__ descs) {
-  const ast_weight_desc_t d = descs[blockIdx.y];
-  if (!d.dwp || !d.grad) return;
-  const size_t n = (size_t)d.Co * d.Ci * d.KK;
-  const float inner = d.u ? d.inner[0] : 0.f;
-  const float inv_sigma = d.u ? 1.f / d.sigma[0] : 1.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const int tap = (int)(i % d.KK);
-    const size_t t = i / d.KK;
-    const int ci = (int)(t % d.Ci), co = (int)(t / d.Ci);
-    const size_t pi = d.dwp_from_wb ? ((size_t)ci * d.KK + tap) * d.Cop + co : ((size_t)co * d.KK + tap) * d.Cip + ci;
-    float gv = d.dwp[pi];
-    if (d.u) gv = (gv - inner * d.u[co] * d.v[ci * d.KK + tap]) * inv_sigma;
-    d.grad[woff(d, co, ci, tap)] += gv;
-  }
-}
-
 // ---- backward --------------------------------------------------------------------
 // inner = <dWp, W>/sigma  -> scratch[0] (zeroed by host)
 __global__ __launch_bounds__(256) void wgrad_inner_kernel(const float* __restrict__ dwp, int from_wb, const float* __restrict__ w,
@@ -191,27 +98,176 @@ __global__ __launch_bounds__(256) void wgrad_unpack_kernel(const float* __restri
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// LDS-tiled forms of pack / flush.  A tile = 32 out-channels x 32 in-channels x all KK taps of one
+// weight (<= 9216 floats).  Global accesses are contiguous runs in every layout:
+//   master w / grad : runs of 32*KK floats along the master's inner channel dimension
+//   wf / dW (wf layout) [co][tap][ci]: runs of 32 ci;   wb / dW (wb layout) [ci][tap][co]: runs of 32 co
+// The permutation between them happens in LDS.  Tiles of all weights of a model are listed in a
+// device array {weight index, co0, ci0} built once by the host.
+// ---------------------------------------------------------------------------
+struct WTile { int w, co0, ci0, pad; };
+constexpr int TL = 32;                       // tile edge (channels)
+constexpr int LP = TL + 1;                   // LDS pitch of the [tap][co][ci] image (floats)
+
+// L[tap][co_l][ci_l] <- master w (coalesced along the master's contiguous dimension)
+__device__ __forceinline__ void tile_load_master(const ast_weight_desc_t& d, const float* __restrict__ base, int co0, int ci0,
+                                                 float* __restrict__ L, float scale) {
+  const bool co_outer = d.s_co >= d.s_ci;    // conv: [co][ci][tap];  convT: [ci][co][tap]
+  const int run = TL * d.KK;                 // contiguous floats per outer index (inner channel x tap)
+  for (int idx = threadIdx.x; idx < TL * run; idx += 256) {
+    const int o = idx / run, r = idx - o * run;
+    const int in = r / d.KK, tap = r - in * d.KK;
+    const int co = co_outer ? co0 + o : co0 + in, ci = co_outer ? ci0 + in : ci0 + o;
+    const float v = (co < d.Co && ci < d.Ci) ? base[(size_t)co * d.s_co + (size_t)ci * d.s_ci + tap] * scale : 0.f;
+    L[(tap * TL + (co - co0)) * LP + (ci - ci0)] = v;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void tile_store_packed(const ast_weight_desc_t& d, int co0, int ci0, const float* __restrict__ L) {
+  // wf[(co*KK + tap)*Cip + ci]: rows (co_l, tap), 32 ci each
+  if (d.wf) {
+    T* wf = (T*)d.wf;
+    for (int idx = threadIdx.x; idx < TL * d.KK * TL; idx += 256) {
+      const int ci_l = idx & (TL - 1), row = idx >> 5;
+      const int tap = row % d.KK, co_l = row / d.KK;
+      const int co = co0 + co_l, ci = ci0 + ci_l;
+      if (co < d.Cop && ci < d.Cip) wf[((size_t)co * d.KK + tap) * d.Cip + ci] = (T)L[(tap * TL + co_l) * LP + ci_l];
+    }
+  }
+  if (d.wb) {
+    T* wb = (T*)d.wb;
+    for (int idx = threadIdx.x; idx < TL * d.KK * TL; idx += 256) {
+      const int co_l = idx & (TL - 1), row = idx >> 5;
+      const int tap = row % d.KK, ci_l = row / d.KK;
+      const int co = co0 + co_l, ci = ci0 + ci_l;
+      if (co < d.Cop && ci < d.Cip) wb[((size_t)ci * d.KK + tap) * d.Cop + co] = (T)L[(tap * TL + co_l) * LP + ci_l];
+    }
+  }
+}
+
+// sigma / u for every spectral-normalised weight (after sn_w_v_kernel); one block per weight
+__global__ __launch_bounds__(256) void sn_sigma_kernel(const ast_weight_desc_t* __restrict__ descs) {
+  __shared__ float red[17];
+  const ast_weight_desc_t d = descs[blockIdx.x];
+  if (d.inner && d.power_iter && threadIdx.x == 0) d.inner[0] = 0.f;
+  if (!d.u) { if (threadIdx.x == 0 && d.sigma) d.sigma[0] = 1.f; return; }
+  float sigma;
+  if (d.power_iter) {
+    float q = 0.f;
+    for (int i = threadIdx.x; i < d.Co; i += 256) q += d.scratch[i] * d.scratch[i];
+    const float nrm = sqrtf(block_sum(q, red));
+    const float inv = 1.f / fmaxf(nrm, 1e-12f);
+    sigma = nrm * nrm * inv;
+    for (int i = threadIdx.x; i < d.Co; i += 256) d.u[i] = d.scratch[i] * inv;
+  } else {
+    float q = 0.f;
+    for (int i = threadIdx.x; i < d.Co; i += 256) q += d.scratch[i] * d.u[i];
+    sigma = block_sum(q, red);
+  }
+  if (threadIdx.x == 0) d.sigma[0] = sigma;
+  __syncthreads();
+  for (int j = threadIdx.x; j < d.Ci * d.KK; j += 256) d.scratch[d.Co + j] = 0.f;   // t = W^T u zeroed for the next forward's atomics
+}
+
+__global__ __launch_bounds__(256) void pack_tiles_kernel(const ast_weight_desc_t* __restrict__ descs, const int* __restrict__ dtypes,
+                                                          const WTile* __restrict__ tiles) {
+  __shared__ float L[9 * TL * LP];
+  const WTile tl = tiles[blockIdx.x];
+  const ast_weight_desc_t d = descs[tl.w];
+  tile_load_master(d, d.w, tl.co0, tl.ci0, L, 1.f / d.sigma[0]);
+  __syncthreads();
+  if (dtypes[tl.w] == AST_BF16) tile_store_packed<bf16_t>(d, tl.co0, tl.ci0, L); else tile_store_packed<float>(d, tl.co0, tl.ci0, L);
+  if (d.dwp && d.power_iter) {                // fresh gradient staging for this step (this tile's slice, both layouts cover it once)
+    for (int idx = threadIdx.x; idx < TL * d.KK * TL; idx += 256) {
+      const int in_l = idx & (TL - 1), row = idx >> 5;
+      const int tap = row % d.KK, out_l = row / d.KK;
+      if (d.dwp_from_wb) { const int ci = tl.ci0 + out_l, co = tl.co0 + in_l; if (ci < d.Cip && co < d.Cop) d.dwp[((size_t)ci * d.KK + tap) * d.Cop + co] = 0.f; }
+      else { const int co = tl.co0 + out_l, ci = tl.ci0 + in_l; if (co < d.Cop && ci < d.Cip) d.dwp[((size_t)co * d.KK + tap) * d.Cip + ci] = 0.f; }
+    }
+  }
+}
+
+// G[tap][co_l][ci_l] <- packed gradient staging (coalesced along its contiguous channel dimension)
+__device__ __forceinline__ void tile_load_dwp(const ast_weight_desc_t& d, int co0, int ci0, float* __restrict__ G) {
+  for (int idx = threadIdx.x; idx < TL * d.KK * TL; idx += 256) {
+    const int in_l = idx & (TL - 1), row = idx >> 5;
+    const int tap = row % d.KK, out_l = row / d.KK;
+    float v = 0.f;
+    int co_l, ci_l;
+    if (d.dwp_from_wb) { ci_l = out_l; co_l = in_l; const int ci = ci0 + ci_l, co = co0 + co_l; if (ci < d.Ci && co < d.Co) v = d.dwp[((size_t)ci * d.KK + tap) * d.Cop + co]; }
+    else { co_l = out_l; ci_l = in_l; const int co = co0 + co_l, ci = ci0 + ci_l; if (co < d.Co && ci < d.Ci) v = d.dwp[((size_t)co * d.KK + tap) * d.Cip + ci]; }
+    G[(tap * TL + co_l) * LP + ci_l] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void flush_inner_tiles_kernel(const ast_weight_desc_t* __restrict__ descs, const WTile* __restrict__ tiles) {
+  __shared__ float G[9 * TL * LP];
+  __shared__ float red[17];
+  const WTile tl = tiles[blockIdx.x];
+  const ast_weight_desc_t d = descs[tl.w];
+  if (!d.dwp || !d.u) return;
+  tile_load_dwp(d, tl.co0, tl.ci0, G);
+  __syncthreads();
+  // walk the master in ITS contiguous order and pick the matching staged gradient from LDS
+  const bool co_outer = d.s_co >= d.s_ci;
+  const int run = TL * d.KK;
+  float q = 0.f;
+  for (int idx = threadIdx.x; idx < TL * run; idx += 256) {
+    const int o = idx / run, r = idx - o * run;
+    const int in = r / d.KK, tap = r - in * d.KK;
+    const int co_l = co_outer ? o : in, ci_l = co_outer ? in : o;
+    const int co = tl.co0 + co_l, ci = tl.ci0 + ci_l;
+    if (co < d.Co && ci < d.Ci) q += G[(tap * TL + co_l) * LP + ci_l] * d.w[(size_t)co * d.s_co + (size_t)ci * d.s_ci + tap];
+  }
+  q = block_sum(q, red);
+  if (threadIdx.x == 0 && q != 0.f) unsafeAtomicAdd(d.inner, q / d.sigma[0]);
+}
+
+__global__ __launch_bounds__(256) void flush_unpack_tiles_kernel(const ast_weight_desc_t* __restrict__ descs, const WTile* __restrict__ tiles) {
+  __shared__ float G[9 * TL * LP];
+  const WTile tl = tiles[blockIdx.x];
+  const ast_weight_desc_t d = descs[tl.w];
+  if (!d.dwp || !d.grad) return;
+  tile_load_dwp(d, tl.co0, tl.ci0, G);
+  __syncthreads();
+  const float inner = d.u ? d.inner[0] : 0.f;
+  const float inv_sigma = d.u ? 1.f / d.sigma[0] : 1.f;
+  const bool co_outer = d.s_co >= d.s_ci;
+  const int run = TL * d.KK;
+  for (int idx = threadIdx.x; idx < TL * run; idx += 256) {
+    const int o = idx / run, r = idx - o * run;
+    const int in = r / d.KK, tap = r - in * d.KK;
+    const int co_l = co_outer ? o : in, ci_l = co_outer ? in : o;
+    const int co = tl.co0 + co_l, ci = tl.ci0 + ci_l;
+    if (co < d.Co && ci < d.Ci) {
+      float gv = G[(tap * TL + co_l) * LP + ci_l];
+      if (d.u) gv = (gv - inner * d.u[co] * d.v[ci * d.KK + tap]) * inv_sigma;
+      d.grad[(size_t)co * d.s_co + (size_t)ci * d.s_ci + tap] += gv;
+    }
+  }
+}
 }  // namespace
 
-// dtypes: device int array [n] giving the packed dtype of each descriptor.
-extern "C" int ast_weights_prepare_v(const ast_weight_desc_t* descs, const int* dtypes, int n, int max_co, int max_cols,
-                                     long max_packed, void* stream) {
-  if (!descs || !dtypes || n <= 0 || max_co <= 0 || max_cols <= 0) AST_FAIL("ast_weights_prepare: bad args");
+extern "C" int ast_weights_prepare_t(const ast_weight_desc_t* descs, const int* dtypes, int n, int max_co, int max_cols,
+                                     const void* tiles, int ntiles, void* stream) {
+  if (!descs || !dtypes || !tiles || n <= 0 || ntiles <= 0 || max_co <= 0 || max_cols <= 0) AST_FAIL("ast_weights_prepare_t: bad args");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(sn_wt_u_kernel, dim3((max_cols + 255) / 256, n, RZ), dim3(256), 0, s, descs);
   hipLaunchKernelGGL(sn_w_v_kernel, dim3((max_co + 3) / 4, n), dim3(256), 0, s, descs);
-  const int nb = (int)std::max(1L, std::min(64L, (max_packed + 2047) / 2048));
-  hipLaunchKernelGGL(sn_pack_kernel, dim3(nb, n), dim3(256), 0, s, descs, dtypes);
+  hipLaunchKernelGGL(sn_sigma_kernel, dim3(n), dim3(256), 0, s, descs);
+  hipLaunchKernelGGL(pack_tiles_kernel, dim3(ntiles), dim3(256), 0, s, descs, dtypes, (const WTile*)tiles);
   AST_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int ast_weight_grads_flush_v(const ast_weight_desc_t* descs, int n, long max_elems, void* stream) {
-  if (!descs || n <= 0) AST_FAIL("ast_weight_grads_flush_v: bad args");
+extern "C" int ast_weight_grads_flush_t(const ast_weight_desc_t* descs, const void* tiles, int ntiles, void* stream) {
+  if (!descs || !tiles || ntiles <= 0) AST_FAIL("ast_weight_grads_flush_t: bad args");
   hipStream_t s = (hipStream_t)stream;
-  const int nb = (int)std::max(1L, std::min(64L, (max_elems + 4095) / 4096));
-  hipLaunchKernelGGL(flush_inner_kernel, dim3(nb, n), dim3(256), 0, s, descs);
-  hipLaunchKernelGGL(flush_unpack_kernel, dim3(nb, n), dim3(256), 0, s, descs);
+  hipLaunchKernelGGL(flush_inner_tiles_kernel, dim3(ntiles), dim3(256), 0, s, descs, (const WTile*)tiles);
+  hipLaunchKernelGGL(flush_unpack_tiles_kernel, dim3(ntiles), dim3(256), 0, s, descs, (const WTile*)tiles);
   AST_CHECK_LAUNCH();
   return 0;
 }

@@ -104,15 +104,14 @@ typedef struct ast_weight_desc_t {
   int32_t dwp_from_wb;  /* 0: dwp is [Cop][KK][Cip]; 1: [Cip][KK][Cop] */
   int32_t pad_;
 } ast_weight_desc_t;
-/* descs: DEVICE array of n descriptors, dtypes: DEVICE int[n] (packed dtype per weight).
- * Runs the power iteration (if requested), sigma = u^T W v, and writes W/sigma in both
- * packed layouts -- three launches for all n weights.  max_co / max_cols / max_packed are
- * the maxima over the descriptors of Co, Ci*KK and Cop*KK*Cip (grid sizing). */
-int ast_weights_prepare_v(const ast_weight_desc_t* descs, const int* dtypes, int n, int max_co, int max_cols,
-                          long max_packed, void* stream);
-/* Batched form of ast_weight_grad_unpack for every descriptor with dwp != NULL: two launches per model
- * (inner products, then grad += (dWp - <dWp,W/sigma> u v^T)/sigma), run once at the end of backward. */
-int ast_weight_grads_flush_v(const ast_weight_desc_t* descs, int n, long max_elems, void* stream);
+/* descs: DEVICE array of n descriptors, dtypes: DEVICE int[n] (packed dtype per weight), tiles: DEVICE array of
+ * {int32 weight index, co0, ci0, pad} covering every 32x32 channel tile of every weight (padded extents).
+ * prepare: power iteration (if requested), sigma = u^T W v, W/sigma written in both packed layouts and the
+ * gradient staging zeroed -- four launches for all n weights; LDS-tiled so every global access is a contiguous run.
+ * flush (once after backward): grad += (dWp - <dWp,W/sigma> u v^T)/sigma for every weight -- two launches. */
+int ast_weights_prepare_t(const ast_weight_desc_t* descs, const int* dtypes, int n, int max_co, int max_cols,
+                          const void* tiles, int ntiles, void* stream);
+int ast_weight_grads_flush_t(const ast_weight_desc_t* descs, const void* tiles, int ntiles, void* stream);
 /* g_orig += (dWp - <dWp,W/sigma> u v^T)/sigma, dWp packed [Cop][KK][Cip] (from_wb=0)
  * or [Cip][KK][Cop] (from_wb=1).  u NULL => plain unpack-accumulate. */
 int ast_weight_grad_unpack(const float* dwp, int from_wb, const float* w, const float* u, const float* v,
