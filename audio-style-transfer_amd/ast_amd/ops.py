@@ -129,7 +129,9 @@ def _wgrad(dy, src, dwp, g):
     if PROFILE is not None:
         e1.record()
         fl, by = _gemm_cost(g, src.element_size(), wgrad=True)
-        PROFILE.append((f"wgrad_kernel<{'bf16' if src.dtype == torch.bfloat16 else 'f32'}>", fl, by, e0, e1))
+        halo = g.ntaps >= 2 and g.Cd <= 32
+        PROFILE.append((f"wgrad{'_halo' if halo else ''}_kernel<{'bf16' if src.dtype == torch.bfloat16 else 'f32'},Cd{min(64, pad8(g.Cd) if g.Cd <= 16 else (32 if g.Cd <= 32 else 64))}>",
+                        fl, by, e0, e1))
 
 
 def acc_grad(p: torch.Tensor) -> torch.Tensor:

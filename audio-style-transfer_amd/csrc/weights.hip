@@ -13,7 +13,7 @@ __device__ __forceinline__ size_t woff(const ast_weight_desc_t& d, int co, int c
 }
 
 // t[j] = sum_co W(co, j) u[co],  j = ci*KK + tap  -> scratch[Co + j]
-// rows are split over grid.z (RZ chunks) and summed with atomics; scratch[Co..] is zeroed by sn_pack_kernel
+// rows are split over grid.z (RZ chunks) and summed with atomics; scratch[Co..] is zeroed by sn_sigma_kernel
 // of the previous forward (and at allocation), so the launch needs no memset.
 constexpr int RZ = 8;
 __global__ __launch_bounds__(256) void sn_wt_u_kernel(const ast_weight_desc_t* __restrict__ descs) {

@@ -98,8 +98,8 @@ typedef struct ast_weight_desc_t {
   void* wb;             /* packed [Cip][KK][Cop]  (rows = in channel) or NULL */
   int32_t Co, Ci, KK, s_co, s_ci, Cop, Cip;
   int32_t power_iter;   /* 1 in training, 0 in eval */
-  float* dwp;           /* packed f32 gradient staging (zeroed by ast_weights_prepare_v in training) or NULL */
-  float* grad;          /* gradient of `w` (same layout as w), accumulated by ast_weight_grads_flush_v */
+  float* dwp;           /* packed f32 gradient staging (zeroed by ast_weights_prepare_t in training) or NULL */
+  float* grad;          /* gradient of `w` (same layout as w), accumulated by ast_weight_grads_flush_t */
   float* inner;         /* [1] scratch: <dWp, W/sigma> */
   int32_t dwp_from_wb;  /* 0: dwp is [Cop][KK][Cip]; 1: [Cip][KK][Cop] */
   int32_t pad_;
