@@ -33,6 +33,11 @@ class WeightDesc(C.Structure):
                [("dwp", vp), ("grad", vp), ("inner", vp), ("dwp_from_wb", i32), ("pad_", i32)]
 
 
+class LinWg(C.Structure):
+    """record of ast_linear_wgrad_batched"""
+    _fields_ = [("dy", vp), ("x", vp), ("dW", vp), ("db", vp)] + [(n, i32) for n in ("M", "N", "K", "lddy", "ldw", "p0", "p1", "p2")]
+
+
 _SIGS = {
     "ast_version": ([], i32),
     "ast_igemm": ([vp, vp, vp, vp, C.POINTER(Gather), i32, i32, vp, C.c_long, vp], i32),
@@ -41,6 +46,7 @@ _SIGS = {
     "ast_wgrad": ([vp, vp, vp, C.POINTER(Gather), i32, vp], i32),
     "ast_skinny_gemm": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "ast_linear_wgrad": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "ast_linear_wgrad_batched": ([vp, i32, i32, vp], i32),
     "ast_nchw_to_nhwc": ([vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, i32, vp], i32),
     "ast_nhwc_to_nchw": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "ast_cast": ([vp, i32, vp, i32, i64, vp], i32),

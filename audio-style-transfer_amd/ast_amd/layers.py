@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import config, ops
-from ._lib import WeightDesc, check, dcode, lib, ptr, stream
+from ._lib import LinWg, WeightDesc, check, dcode, lib, ptr, stream
 from .ops import PackedWeight, pad8
 
 
@@ -30,6 +30,11 @@ class WeightBank:
         self._key = None
         self._keys = {}
         self._flush_pending = False
+        self._lin_deferred = []       # (PackedWeight, dy, x) of this backward pass, weight gradients computed in one launch
+        self._pinned = []             # pointer tables referenced by captured memcpy nodes must outlive the graph
+        self._pin_pool = None         # pinned host memory for those tables, allocated outside capture
+        self._pin_used = 0
+        self._conv_dirty = False
         self.d_train = self.d_eval = None
         self.hold = False     # True: packed images are current (several forwards between optimiser steps)
 
@@ -104,6 +109,8 @@ class WeightBank:
             for co0 in range(0, e.Cop, 32):
                 for ci0 in range(0, e.Cip, 32):
                     tl += [wi, co0, ci0, 0]
+        if self._pin_pool is None:
+            self._pin_pool = torch.empty(256 * 1024, dtype=torch.uint8, pin_memory=True)
         self.ntiles = len(tl) // 4
         self.d_tiles = torch.tensor(tl, dtype=torch.int32, device=dev)
         arr = (WeightDesc * len(descs))(*descs)
@@ -126,15 +133,48 @@ class WeightBank:
                                           ptr(self.d_tiles), self.ntiles, stream()), "ast_weights_prepare_t")
 
     # ---- batched weight-gradient unpack, once per backward pass ----------------------
-    def request_flush(self):
+    def defer_linear_wgrad(self, pw, dy, x):
+        self._lin_deferred.append((pw, dy, x))
+        self.request_flush(conv=False)
+
+    def request_flush(self, conv=True):
+        self._conv_dirty = self._conv_dirty or conv
         if not self._flush_pending:
             self._flush_pending = True
             torch.autograd.Variable._execution_engine.queue_callback(self._flush)
 
     def _flush(self):
         self._flush_pending = False
-        check(lib().ast_weight_grads_flush_t(ptr(self.d_train), ptr(self.d_tiles), self.ntiles, stream()),
-              "ast_weight_grads_flush_t")
+        if self._conv_dirty:
+            self._conv_dirty = False
+            check(lib().ast_weight_grads_flush_t(ptr(self.d_train), ptr(self.d_tiles), self.ntiles, stream()),
+                  "ast_weight_grads_flush_t")
+        if self._lin_deferred:
+            items, self._lin_deferred = self._lin_deferred, []
+            recs, max_tiles = [], 1
+            for pw, dy, x in items:
+                gw = ops.acc_grad(pw.weight)
+                gb = 0 if pw.bias is None else ops.acc_grad(pw.bias).data_ptr() + 4 * pw.b_off
+                recs.append(LinWg(dy=dy.data_ptr(), x=x.data_ptr(), dW=gw.data_ptr() + 4 * pw.w_off, db=gb or None, M=x.shape[0],
+                                  N=pw.Co, K=pw.Ci, lddy=pw.Cop, ldw=pw.s_co, p0=0, p1=0, p2=0))
+                max_tiles = max(max_tiles, ((pw.Ci + 63) // 64) * ((pw.Co + 63) // 64))
+            arr = (LinWg * len(recs))(*recs)
+            nbytes = C.sizeof(arr)
+            dev = torch.empty(nbytes, dtype=torch.uint8, device=items[0][1].device)
+            if torch.cuda.is_current_stream_capturing():
+                # captured: the table comes from a pinned pool allocated BEFORE capture (no allocation is allowed now);
+                # the H2D copy becomes a memcpy node that re-reads the (persistent, unchanging) host slice at every replay
+                if self._pin_pool is None or self._pin_used + nbytes > self._pin_pool.numel():
+                    raise RuntimeError("weight bank: pinned pointer-table pool exhausted (run one eager warm-up step first)")
+                host = self._pin_pool[self._pin_used:self._pin_used + nbytes]
+                self._pin_used += (nbytes + 63) // 64 * 64
+                C.memmove(host.data_ptr(), C.addressof(arr), nbytes)
+                dev.copy_(host, non_blocking=True)
+                self._pinned.append((host, dev, items))  # device table and the operand tensors stay valid for replays
+            else:
+                host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+                dev.copy_(host)                          # pageable, blocking on the host side: safe to drop right away
+            check(lib().ast_linear_wgrad_batched(ptr(dev), len(recs), max_tiles, stream()), "ast_linear_wgrad_batched")
 
 
 def img_dtype():

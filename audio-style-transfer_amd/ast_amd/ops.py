@@ -289,10 +289,13 @@ class LinearFn(torch.autograd.Function):
             dy = dz
         dx = None
         if ctx.skinny:
-            gw = acc_grad(pw.weight)
-            gb = None if pw.bias is None else acc_grad(pw.bias).data_ptr() + 4 * pw.b_off
-            check(lib().ast_linear_wgrad(ptr(dy), ptr(x), gw.data_ptr() + 4 * pw.w_off, gb, rows, pw.Co, pw.Ci, pw.Cop, pw.s_co,
-                                         stream()), "ast_linear_wgrad")
+            if pw.bank is not None:
+                pw.bank.defer_linear_wgrad(pw, dy, x)      # all dW/db of the model in ONE launch after backward
+            else:
+                gw = acc_grad(pw.weight)
+                gb = None if pw.bias is None else acc_grad(pw.bias).data_ptr() + 4 * pw.b_off
+                check(lib().ast_linear_wgrad(ptr(dy), ptr(x), gw.data_ptr() + 4 * pw.w_off, gb, rows, pw.Co, pw.Ci, pw.Cop, pw.s_co,
+                                             stream()), "ast_linear_wgrad")
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)       # dx[m][k] = sum_n dy[m][n] Wt[k][n], Wt = packed [Ci][Cop]
                 check(lib().ast_skinny_gemm(ptr(dy), ptr(pw.wb), None, ptr(dx), rows, pw.Ci, pw.Cop, pw.Cop, pw.Cip, 0, stream()),

@@ -116,7 +116,71 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     if (g == 0 && nv) db[n0 + i] += bsum;
   }
 }
+// Batched form: one launch for every deferred linear weight gradient of a model.
+// table[e] = {dy, x, dW, db, M, N, K, lddy, ldw}; blockIdx.y = entry, blockIdx.x = (k tile, n tile-of-64) of that entry.
+struct LinWg { const float* dy; const float* x; float* dW; float* db; int M, N, K, lddy, ldw, pad0, pad1, pad2; };
+
+__global__ __launch_bounds__(256) void linear_wgrad_batched_kernel(const LinWg* __restrict__ table) {
+  const LinWg e = table[blockIdx.y];
+  const int ktiles = (e.K + 63) / 64, ntiles = (e.N + 63) / 64;
+  if ((int)blockIdx.x >= ktiles * ntiles) return;
+  const int kt = blockIdx.x % ktiles, nt = blockIdx.x / ktiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int n0 = (nt * 4 + wave) * 16, k0 = kt * 64;
+  if (n0 >= e.N) return;
+  const bool nv = n0 + i < e.N;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  for (int st0 = 0; st0 * 4 < e.M; st0 += 4) {          // 4 MFMA k-steps (16 token rows) per batch of loads
+    float av[4], bv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = (st0 + u) * 4 + g;
+      const bool mv = m < e.M;
+      const float a = e.dy[(size_t)(mv ? m : 0) * e.lddy + (nv ? n0 + i : 0)];
+      av[u] = (mv && nv) ? a : 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int k = k0 + t * 16 + i;
+        const bool kv = mv && k < e.K;
+        const float b = e.x[(size_t)(kv ? m : 0) * e.K + (kv ? k : 0)];
+        bv[u][t] = kv ? b : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bsum += av[u];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][t], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int k = k0 + t * 16 + i;
+    if (k >= e.K) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * g + r;
+      if (n < e.N) e.dW[(size_t)n * e.ldw + k] += acc[t][r];
+    }
+  }
+  if (e.db && kt == 0) {
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (g == 0 && nv) e.db[n0 + i] += bsum;
+  }
+}
 }  // namespace
+
+extern "C" int ast_linear_wgrad_batched(const void* table, int count, int max_tiles, void* stream) {
+  if (!table || count <= 0 || max_tiles <= 0) AST_FAIL("ast_linear_wgrad_batched: bad args");
+  hipLaunchKernelGGL(linear_wgrad_batched_kernel, dim3(max_tiles, count), dim3(256), 0, (hipStream_t)stream, (const LinWg*)table);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int ast_skinny_gemm(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldw, int ldy,
                                int relu, void* stream) {

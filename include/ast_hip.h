@@ -78,6 +78,11 @@ int ast_skinny_gemm(const float* x, const float* w, const float* bias, float* y,
 int ast_linear_wgrad(const float* dy, const float* x, float* dW, float* db, int M, int N, int K, int lddy, int ldw,
                      void* stream);
 
+/* Batched ast_linear_wgrad: table = DEVICE array of `count` records
+ * {const float* dy, x; float* dW, db; int32 M, N, K, lddy, ldw, pad[3]} (64 bytes each); max_tiles >= max over
+ * records of ceil(K/64)*ceil(N/64).  One launch for every linear layer of a model, after backward. */
+int ast_linear_wgrad_batched(const void* table, int count, int max_tiles, void* stream);
+
 /* ---- layout conversion at the module boundary ------------------------------ */
 /* x (N,C,H,W) f32, element (n,c,h,w) at n*sn + c*sc + h*sh + w  ->  NHWC dtype, Cp>=C zero padded.
  * Replaces the implicit NCHW contract of x.view(B*S,C,T,F) (style_encoder.py:213). */
