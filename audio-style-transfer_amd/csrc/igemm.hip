@@ -82,8 +82,12 @@ __device__ __forceinline__ int swz(int row, int c) { return ((c + (((row >> 3) &
 // ([M][Cd]) with atomics and splitk_finish_kernel applies bias / accumulate / ReLU / cast.
 // Operands are read with buffer_load_dwordx4: masked lanes get an out-of-range offset and the
 // hardware returns zeros (no select, no 64-bit address arithmetic).
-template <typename T, int BM, int BN, int WM, int WN, int KCH, int D>
-__global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, const T* __restrict__ wgt,
+// UT ("uniform tap"): Cs/E is a multiple of KCH, so all KCH chunks of a K tile belong to one tap.  The tap decode and
+// the source / weight byte deltas are then wave-uniform and live in SGPRs; per load a lane only tests one bit of a
+// per-row tap-validity mask built once, and adds the scalar delta.  (The general path costs ~7 VALU per MFMA, which
+// is what bounds the kernel: the deep layers ran at the same speed for every tile shape and K split.)
+template <typename T, int BM, int BN, int WM, int WN, int KCH, int D, int KG, bool UT>
+__global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ src, const T* __restrict__ wgt,
                                                      const float* __restrict__ bias, T* __restrict__ dst,
                                                      const ast_gather_t g, const int M, const int flags,
                                                      float* __restrict__ ws, const int kt_per_split, const int cpc_shift,
@@ -97,18 +101,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
   constexpr int TM = WTM / 16, TN = WTN / 16;
   constexpr int AI = BM / RPP, BI = (BN + RPP - 1) / RPP;
   constexpr int SUBB = (BM + BN) * 64;       // bytes of one sub-tile (A rows then B rows)
-  constexpr unsigned OOB = 0x80000000u;
-  static_assert(WM * WN == 4 && BM % RPP == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile");
+  constexpr unsigned OOB = 0x80000000u, OOBH = 0x40000000u;
+  static_assert(WM * WN == 4 && BM % RPP == 0 && WTM % 16 == 0 && WTN % 16 == 0 && D % 2 == 0, "tile");
   using frag = typename Mma<T>::frag;
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // 2 * NSUB * SUBB, then 16 ints
-  int* taptab = reinterpret_cast<int*>(lds + 2 * NSUB * SUBB);
+  // KG > 1: the workgroup has KG groups of 4 waves; group kg streams K tiles kt0+kg, kt0+kg+KG, ... through its own
+  // LDS buffers and the partial accumulators are summed through LDS at the end.  For the deep layers (M of a few
+  // thousand rows, K up to 4608) this puts KG times more loads in flight per CU and cuts the serial K loop by KG,
+  // without the atomics + finish pass of a grid-level split.
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];  // KG * (2 * NSUB * SUBB), then 16 ints
+  int* taptab = reinterpret_cast<int*>(lds_all + KG * 2 * NSUB * SUBB);
+  const int kg = KG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;   // wave-uniform
+  unsigned char* lds = lds_all + kg * (2 * NSUB * SUBB);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int cc = tid % KCH, r0 = tid / KCH;
   const int csub = cc >> 2, cch = cc & 3;
-  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so XCD x takes
+  // the x-th contiguous eighth of the tiles in N-major order: its L2 then holds one slice of the weights and one
+  // contiguous band of source rows (with its 3x3 halo) instead of a sample of everything.  Speed only; any
+  // placement gives the same result.
+  const int MT = (M + BM - 1) / BM, NT = (g.Cd + BN - 1) / BN;
+  const int chunk = gridDim.x >> 3;
+  const int tix = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tix >= MT * NT) return;
+  const int ntile = tix / MT;
+  const int bm0 = (tix - ntile * MT) * BM, bn0 = ntile * BN;
   const int cpc = g.Cs / E;
   const int nchunks = g.ntaps * cpc;
   const int KT = (nchunks + KCH - 1) / KCH;
@@ -119,7 +138,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
 
 #pragma unroll
   for (int t = 0; t < AST_MAX_TAPS; ++t)
-    if (tid == t) taptab[t] = g.tap[t];          // static index: a dynamic one would spill the by-value struct to scratch
+    if ((int)threadIdx.x == t) taptab[t] = g.tap[t];   // static index: a dynamic one would spill the by-value struct to scratch
 
   int roff[AI], rhs0[AI], rws0[AI];              // source byte offset of the row's base pixel (negative for halo rows)
 #pragma unroll
@@ -140,6 +159,29 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
     boff[i] = (row < BN && co < g.Cd) ? (unsigned)(co * g.wtaps * g.Cs * ES) : OOB;
   }
   __syncthreads();
+  unsigned rmask[AI];                            // UT: bit t = tap t of this row lies inside the source image
+  if constexpr (UT) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) { rmask[i] = 0; roff[i] += cc * 16; }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) boff[i] = boff[i] == OOB ? OOBH : boff[i] + cc * 16;
+#pragma unroll
+    for (int t = 0; t < AST_MAX_TAPS; ++t) {
+      if (t < g.ntaps) {
+        int dh, dw, wt;
+        decode_tap(__builtin_amdgcn_readfirstlane(taptab[t]), dh, dw, wt);
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+          if ((unsigned)(rhs0[i] + dh) < (unsigned)g.Hs && (unsigned)(rws0[i] + dw) < (unsigned)g.Ws) rmask[i] |= 1u << t;
+      }
+    }
+    // keep the per-row bases as opaque registers: otherwise the optimiser re-derives them from (n, h, w) inside the
+    // K loop to save VGPRs, which puts two quarter-rate v_mul_lo_u32 per load back into it
+#pragma unroll
+    for (int i = 0; i < AI; ++i) asm volatile("" : "+v"(roff[i]), "+v"(rmask[i]));
+#pragma unroll
+    for (int i = 0; i < BI; ++i) asm volatile("" : "+v"(boff[i]));
+  }
 
   f32x4 acc[TN][TM];
 #pragma unroll
@@ -152,9 +194,29 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
   // latency-bound).  The K loop is unrolled by D so every stage index is a compile-time constant.
   u32x4 areg[D][AI], breg[D][BI];
 
-  auto load_tile = [&](int kt, u32x4 (&ar)[AI], u32x4 (&br)[BI]) __attribute__((always_inline)) {
+  const int nkt = kt1 - kt0;
+  auto load_tile = [&](int j, u32x4 (&ar)[AI], u32x4 (&br)[BI]) __attribute__((always_inline)) {
+    const bool jval = j < nkt;
+    const int kt = kt0 + j;
+    if constexpr (UT) {
+      const int kc0 = kt * KCH;                              // everything down to the per-row select is scalar
+      const bool kval = jval;
+      const int t = kval ? (cpc_shift >= 0 ? (kc0 >> cpc_shift) : kc0 / cpc) : 0;
+      const int c0b = (kc0 - t * cpc) * 16;
+      int dh, dw, wt;
+      decode_tap(__builtin_amdgcn_readfirstlane(taptab[t]), dh, dw, wt);
+      const int sdelta = (dh * g.Ws + dw) * g.Cs * ES + c0b;
+      const unsigned tbit = kval ? (1u << t) : 0u;
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+        ar[i] = __builtin_amdgcn_raw_buffer_load_b128(srcR, (rmask[i] & tbit) ? (unsigned)(roff[i] + sdelta) : OOB, 0, 0);
+      const unsigned swoff = kval ? (unsigned)(wt * g.Cs * ES + c0b) : OOBH;
+#pragma unroll
+      for (int i = 0; i < BI; ++i) br[i] = __builtin_amdgcn_raw_buffer_load_b128(wgtR, boff[i] + swoff, 0, 0);
+      return;
+    }
     const int kc = kt * KCH + cc;
-    const bool kval = kc < nchunks && kt < kt1;
+    const bool kval = kc < nchunks && jval;
     const int t = kval ? (cpc_shift >= 0 ? (kc >> cpc_shift) : kc / cpc) : 0;
     const int c0 = (kc - t * cpc) * E;
     int dh, dw, wt;
@@ -193,15 +255,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
   for (int i = 0; i < TN; ++i) boffs[i] = (BM + wn * WTN + i * 16 + fr) * 64 + fsw;
 
 #pragma unroll
-  for (int st = 0; st < D; ++st) load_tile(kt0 + st, areg[st], breg[st]);
-  for (int ktb = kt0; ktb < kt1; ktb += D) {
+  for (int st = 0; st < D; ++st) load_tile(kg + st * KG, areg[st], breg[st]);
+  // every group runs the same number of iterations (its tail tiles are masked to zeros) so the
+  // workgroup-wide barrier below is reached uniformly
+  const int niter = (kt1 - kt0 + KG - 1) / KG;
+  for (int itb = 0; itb < niter; itb += D) {
 #pragma unroll
     for (int st = 0; st < D; ++st) {
-      const int kt = ktb + st;
-      if (kt < kt1) {                                        // uniform per workgroup
-        const int cur = (kt - kt0) & 1;
+      const int it = itb + st;
+      if (it < niter) {                                      // uniform per workgroup
+        const int j = kg + it * KG;
+        const int cur = st & 1;                               // itb is a multiple of D (even): it & 1 == st & 1, a constant
         store_tile(cur, areg[st], breg[st]);                 // waits (counted vmcnt) for this stage's loads only
-        load_tile(kt + D, areg[st], breg[st]);
+        load_tile(j + D * KG, areg[st], breg[st]);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < NSUB; ++ks) {
@@ -220,6 +286,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ src, c
     }
   }
 
+  if constexpr (KG > 1) {                                     // sum the K-groups' partial tiles through LDS
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(lds_all);
+    if (kg > 0) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) red[(((kg - 1) * TN + i) * TM + j) * 256 + tid] = acc[i][j];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int q = 0; q < KG - 1; ++q)
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const f32x4 t = red[((q * TN + i) * TM + j) * 256 + tid];
+          acc[i][j][0] += t[0]; acc[i][j][1] += t[1]; acc[i][j][2] += t[2]; acc[i][j][3] += t[3];
+        }
+  }
   // epilogue: lane owns pixel (col) fr of tile j and channels fq*4..fq*4+3 (rows) of tile i
   const bool accumulate = flags & 1, relu = flags & 2;
   const bool split = gridDim.z > 1;
@@ -706,7 +793,7 @@ int launch_wgrad_halo(const void* dy, const void* src, float* dw, const ast_gath
   return 0;
 }
 
-struct IgemmPlan { int bm, bn, kch, nsplit, kt_per_split, depth; };
+struct IgemmPlan { int bm, bn, kch, nsplit, kt_per_split, depth, kgroups; };
 
 IgemmPlan plan_igemm(const ast_gather_t& g, int M, int dtype) {
   const int E = dtype == AST_BF16 ? 8 : 4;
@@ -722,13 +809,17 @@ IgemmPlan plan_igemm(const ast_gather_t& g, int M, int dtype) {
   const int KT = (nchunks + p.kch - 1) / p.kch;
   const long blocks = (long)((M + p.bm - 1) / p.bm) * ((g.Cd + p.bn - 1) / p.bn);
   p.nsplit = 1;
-  if (blocks < 200 && KT >= 16 && (long)M * g.Cd <= (1L << 20)) p.nsplit = blocks < 120 ? 4 : 2;
+  p.kgroups = 1;
+  // under-filled grid with a long K loop: split K inside the workgroup (sweep: b5 35 -> 24 us, b4 47 -> 41 us; b3, with
+  // 684 tiles, loses)
+  if (p.bm == 64 && p.bn == 64 && blocks < 400 && KT >= 16) { p.kgroups = 4; p.kch = 4; }
+  else if (blocks < 200 && KT >= 16 && (long)M * g.Cd <= (1L << 20)) p.nsplit = blocks < 120 ? 4 : 2;
   p.depth = 2;                                          // depth 4 measured no better (the loop is not latency-bound)
-  if (const char* f = getenv("AST_IGEMM_FORCE")) {      // tuning aid: "bm,bn,kch,nsplit[,depth]"
+  if (const char* f = getenv("AST_IGEMM_FORCE")) {      // tuning aid: "bm,bn,kch,nsplit[,kgroups]"
     int a, b, c, d, e = 0;
     const int nf = sscanf(f, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &e);
-    if (nf >= 4) { p.bm = a; p.bn = b; p.kch = c; p.nsplit = std::max(1, d); p.depth = 2; }
-    if (nf == 5) p.depth = e;
+    if (nf >= 4) { p.bm = a; p.bn = b; p.kch = c; p.nsplit = std::max(1, d); p.depth = 2; p.kgroups = 1; }
+    if (nf >= 5) p.kgroups = (e == 4 && a == 64 && b == 64) ? 4 : 1;
   }
   {
     const int KT2 = (nchunks + p.kch - 1) / p.kch;
@@ -740,24 +831,26 @@ IgemmPlan plan_igemm(const ast_gather_t& g, int M, int dtype) {
   return p;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KCH, int D>
-int launch_igemm(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t& g, int M, int flags,
+template <typename T, int BM, int BN, int WM, int WN, int KCH, int D, int KG, bool UT>
+int launch_igemm_ut(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t& g, int M, int flags,
                  float* ws, const IgemmPlan& p, hipStream_t s) {
-  constexpr int LDS = 2 * (KCH / 4) * (BM + BN) * 64 + 64;
+  constexpr int LDS = KG * 2 * (KCH / 4) * (BM + BN) * 64 + 64;
+  static_assert(KG == 1 || (KG - 1) * (BM / 16) * (BN / 16) / 4 * 256 * 16 <= KG * 2 * (KCH / 4) * (BM + BN) * 64, "reduce buffer fits");
   static bool attr_set = false;
   if (!attr_set) {
-    AST_HIP(hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, KCH, D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    AST_HIP(hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, KCH, D, KG, UT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   const int E = 16 / sizeof(T);
   const int cpc = g.Cs / E;
   int shift = -1;
   if ((cpc & (cpc - 1)) == 0) { shift = 0; while ((1 << shift) < cpc) ++shift; }
-  dim3 grid((M + BM - 1) / BM, (g.Cd + BN - 1) / BN, p.nsplit);
+  const int tiles = ((M + BM - 1) / BM) * ((g.Cd + BN - 1) / BN);
+  dim3 grid((tiles + 7) / 8 * 8, 1, p.nsplit);
   if (p.nsplit > 1 && !(flags & 4)) AST_HIP(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)M * g.Cd, s));
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
   const unsigned wgt_bytes = (unsigned)((size_t)g.Cd * g.wtaps * g.Cs * sizeof(T));
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KCH, D>), grid, dim3(256), LDS, s, (const T*)src, (const T*)wgt, bias, (T*)dst, g, M,
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KCH, D, KG, UT>), grid, dim3(256 * KG), LDS, s, (const T*)src, (const T*)wgt, bias, (T*)dst, g, M,
                      flags, ws, p.kt_per_split, shift, src_bytes, wgt_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm);
   if (p.nsplit > 1) {
     const size_t total = (size_t)M * (g.Cd >> 2);
@@ -766,6 +859,14 @@ int launch_igemm(const void* src, const void* wgt, const float* bias, void* dst,
   }
   AST_CHECK_LAUNCH();
   return 0;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int KCH, int D, int KG>
+int launch_igemm(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t& g, int M, int flags,
+                 float* ws, const IgemmPlan& p, hipStream_t s) {
+  const int cpc = g.Cs / (16 / (int)sizeof(T));
+  if (cpc % KCH == 0) return launch_igemm_ut<T, BM, BN, WM, WN, KCH, D, KG, true>(src, wgt, bias, dst, g, M, flags, ws, p, s);
+  return launch_igemm_ut<T, BM, BN, WM, WN, KCH, D, KG, false>(src, wgt, bias, dst, g, M, flags, ws, p, s);
 }
 
 int check_gather(const ast_gather_t* g, const char* who) {
@@ -794,7 +895,7 @@ extern "C" long ast_igemm_ws_floats(const ast_gather_t* gp, int dtype) {
 extern "C" int ast_igemm_plan(const ast_gather_t* gp, int dtype, int* out5) {
   if (!gp || !out5 || check_gather(gp, "ast_igemm_plan")) return -1;
   const IgemmPlan p = plan_igemm(*gp, gp->N * gp->Hm * gp->Wm, dtype);
-  out5[0] = p.bm; out5[1] = p.bn; out5[2] = p.kch; out5[3] = p.nsplit; out5[4] = p.depth;
+  out5[0] = p.bm; out5[1] = p.bn; out5[2] = p.kch; out5[3] = p.nsplit; out5[4] = p.kgroups;
   return 0;
 }
 
@@ -807,11 +908,12 @@ extern "C" int ast_igemm(const void* src, const void* wgt, const float* bias, vo
   hipStream_t s = (hipStream_t)stream;
   IgemmPlan p = plan_igemm(g, M, dtype);
   if (p.nsplit > 1 && (!ws || ws_floats < (long)M * g.Cd)) AST_FAIL("ast_igemm: split-K needs a workspace of %ld floats (ast_igemm_ws_floats)", (long)M * g.Cd);
-#define AST_IG(BM_, BN_, WM_, WN_, K_) do { if (p.depth >= 4) return launch_igemm<T, BM_, BN_, WM_, WN_, K_, 4>(src, wgt, bias, dst, g, M, flags, ws, p, s); \
-    return launch_igemm<T, BM_, BN_, WM_, WN_, K_, 2>(src, wgt, bias, dst, g, M, flags, ws, p, s); } while (0)
+#define AST_IG(BM_, BN_, WM_, WN_, K_) return launch_igemm<T, BM_, BN_, WM_, WN_, K_, 2, 1>(src, wgt, bias, dst, g, M, flags, ws, p, s)
+#define AST_IG4(BM_, BN_, WM_, WN_, K_) return launch_igemm<T, BM_, BN_, WM_, WN_, K_, 2, 4>(src, wgt, bias, dst, g, M, flags, ws, p, s)
   AST_DISPATCH_T(dtype, {
     if (p.bm == 128 && p.bn == 128) { if (p.kch == 8) AST_IG(128, 128, 2, 2, 8); else AST_IG(128, 128, 2, 2, 4); }
     if (p.bm == 128 && p.bn == 64) { if (p.kch == 8) AST_IG(128, 64, 2, 2, 8); else AST_IG(128, 64, 2, 2, 4); }
+    if (p.bm == 64 && p.bn == 64 && p.kgroups == 4) { if (p.kch == 8) AST_IG4(64, 64, 2, 2, 8); else AST_IG4(64, 64, 2, 2, 4); }
     if (p.bm == 64 && p.bn == 64) { if (p.kch == 8) AST_IG(64, 64, 2, 2, 8); else AST_IG(64, 64, 2, 2, 4); }
     if (p.bm == 64 && p.bn == 128) { if (p.kch == 8) AST_IG(64, 128, 1, 4, 8); else AST_IG(64, 128, 1, 4, 4); }
     if (p.bm == 128 && p.bn == 32) AST_IG(128, 32, 4, 1, 4);
@@ -822,6 +924,7 @@ extern "C" int ast_igemm(const void* src, const void* wgt, const float* bias, vo
     AST_IG(64, 16, 4, 1, 4);
   });
 #undef AST_IG
+#undef AST_IG4
   return 0;
 }
 

@@ -61,7 +61,7 @@ int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst,
 /* f32 workspace (floats) ast_igemm needs for this geometry: >0 when the launch is split over K
  * (under-filled grids of the deep, small-M layers), 0 otherwise, <0 on a bad geometry. */
 long ast_igemm_ws_floats(const ast_gather_t* g, int dtype);
-/* the tile plan ast_igemm will use: out5 = {BM, BN, 16-byte chunks per row per barrier, split-K slices, prefetch depth} */
+/* the tile plan ast_igemm will use: out5 = {BM, BN, 16-byte chunks per row per barrier, grid-level split-K slices, in-workgroup K groups} */
 int ast_igemm_plan(const ast_gather_t* g, int dtype, int* out5);
 
 /* dw[cd][wtap[t]][c] += sum_pix dy[pix][cd] * src[gather(pix,t)][c]   (f32 atomics)

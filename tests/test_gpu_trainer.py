@@ -33,8 +33,10 @@ def test_trainer_modes_agree():
     for mode in ((False, True, 3, False), (True, True, 3, False), (True, True, 3, True)):   # last: the 3-graph form DP uses
         hist, s, a, _ = _run(*mode)
         for i, (h, r) in enumerate(zip(hist, ref_hist)):
-            tol = 2e-4 if i == 0 else 5e-3        # f32-atomic summation order differs run to run and compounds over steps
             for k in r:
+                # f32-atomic summation order differs run to run and compounds over steps; adv_g / total sit behind the
+                # discriminator's sign-sensitive first Adam update (two identical eager runs differ by 3e-4 there)
+                tol = 5e-3 if i > 0 else (2e-3 if k in ("adv_g", "total") else 2e-4)
                 assert math.isclose(h[k], r[k], rel_tol=tol, abs_tol=1e-5), (mode, i, k, h[k], r[k])
         assert math.isclose(a, ref_abs, rel_tol=1e-6), (mode, a, ref_abs)
 
@@ -64,5 +66,9 @@ def test_frontend_in_step_matches_prefilled_input():
     b = train.Trainer(train.TrainConfig(use_graph=True, dropout=False), seed=3)
     b.set_frontend(waves, mean, std)
     rb = {k: float(v) for k, v in b.step(x.clone(), labels).items()}
+    # adv_g (and through it total) is evaluated after the discriminator's Adam step, whose first update is +-lr per
+    # parameter whatever the gradient's size: atomic-order noise in near-zero gradients flips signs, and the spread
+    # between two identical eager runs is already 3e-4 (tools/noise.py)
     for k in ra:
-        assert math.isclose(ra[k], rb[k], rel_tol=2e-4, abs_tol=1e-6), (k, ra[k], rb[k])
+        tol = 2e-3 if k in ("adv_g", "total") else 2e-4
+        assert math.isclose(ra[k], rb[k], rel_tol=tol, abs_tol=1e-6), (k, ra[k], rb[k])

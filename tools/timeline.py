@@ -36,5 +36,5 @@ agg = collections.defaultdict(lambda: [0, 0])
 for s, e, n in step:
     key = n.replace("(anonymous namespace)::", "").replace("_ZN12_GLOBAL__N_1", "").replace("void ", "")[:44]
     agg[key][0] += 1; agg[key][1] += e - s
-for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[2]) if len(sys.argv) > 2 else 14]:
     print(f"  {k:44s} {c:4d} {t/1e3:8.1f}us")
