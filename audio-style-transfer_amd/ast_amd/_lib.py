@@ -45,6 +45,7 @@ _SIGS = {
     "ast_igemm_ws_floats": ([C.POINTER(Gather), i32], C.c_long),
     "ast_wgrad": ([vp, vp, vp, C.POINTER(Gather), i32, vp], i32),
     "ast_skinny_gemm": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "ast_skinny_gemm_ex": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, f32, C.c_uint64, vp, vp], i32),
     "ast_linear_wgrad": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "ast_linear_wgrad_batched": ([vp, i32, i32, vp], i32),
     "ast_nchw_to_nhwc": ([vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, i32, vp], i32),
@@ -62,6 +63,8 @@ _SIGS = {
     "ast_norm_bwd_apply": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "ast_layernorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp], i32),
     "ast_layernorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),
+    "ast_add_drop_ln_fwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, C.c_uint64, vp, vp], i32),
+    "ast_add_drop_ln_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),
     "ast_adaptive_pool_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "ast_adaptive_pool_bwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "ast_bilinear_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),

@@ -12,3 +12,9 @@ def set_compute_dtype(dtype):
     if dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
     compute_dtype = dtype
+
+
+# Token-path fusions (residual + dropout + LayerNorm in one launch, the FFN in two).  The per-op path is kept as
+# the reference the fused kernels are tested against; AST_FUSED_TOKENS=0 selects it for A/B timing.
+import os as _os
+fused_tokens = _os.environ.get("AST_FUSED_TOKENS", "1") != "0"

@@ -250,10 +250,15 @@ class EncoderLayer:
     def __call__(self, x, training):
         l, p = self.l, self.l.dropout.p
         B, L, d = x.shape
-        x = layer_norm(x + ops.dropout(self.attn(x, None, training, l.self_attn.dropout), l.dropout1.p, training), l.norm1)
-        h = ops.dropout(linear(x.reshape(B * L, d), self.ff1, relu=True), p, training)
-        h = ops.dropout(linear(h, self.ff2), l.dropout2.p, training).view(B, L, d)
-        return layer_norm(x + h, l.norm2)
+        if not config.fused_tokens:
+            x = layer_norm(x + ops.dropout(self.attn(x, None, training, l.self_attn.dropout), l.dropout1.p, training), l.norm1)
+            h = ops.dropout(linear(x.reshape(B * L, d), self.ff1, relu=True), p, training)
+            h = ops.dropout(linear(h, self.ff2), l.dropout2.p, training).view(B, L, d)
+            return layer_norm(x + h, l.norm2)
+        _, x = ops.add_drop_ln(x, self.attn(x, None, training, l.self_attn.dropout), l.norm1, l.dropout1.p, training)
+        h = ops.ffn(x.reshape(B * L, d), self.ff1, self.ff2, p, training)
+        _, y = ops.add_drop_ln(x, h.view(B, L, d), l.norm2, l.dropout2.p, training)
+        return y
 
 
 class DecoderLayer:
@@ -269,11 +274,18 @@ class DecoderLayer:
     def __call__(self, x, memory, training):
         l = self.l
         B, L, d = x.shape
+        if not config.fused_tokens:
+            h = layer_norm(x, l.norm1)
+            x = x + ops.dropout(self.sa(h, None, training, l.self_attn.dropout, causal=True), l.dropout1.p, training)
+            h = layer_norm(x, l.norm2)
+            x = x + ops.dropout(self.ca(h, memory, training, l.multihead_attn.dropout), l.dropout2.p, training)
+            h = layer_norm(x, l.norm3)
+            h = ops.dropout(linear(h.reshape(B * L, d), self.ff1, relu=True), l.dropout.p, training)
+            h = ops.dropout(linear(h, self.ff2), l.dropout3.p, training).view(B, L, d)
+            return x + h
         h = layer_norm(x, l.norm1)
-        x = x + ops.dropout(self.sa(h, None, training, l.self_attn.dropout, causal=True), l.dropout1.p, training)
-        h = layer_norm(x, l.norm2)
-        x = x + ops.dropout(self.ca(h, memory, training, l.multihead_attn.dropout), l.dropout2.p, training)
-        h = layer_norm(x, l.norm3)
-        h = ops.dropout(linear(h.reshape(B * L, d), self.ff1, relu=True), l.dropout.p, training)
-        h = ops.dropout(linear(h, self.ff2), l.dropout3.p, training).view(B, L, d)
-        return x + h
+        x, h = ops.add_drop_ln(x, self.sa(h, None, training, l.self_attn.dropout, causal=True), l.norm2, l.dropout1.p, training)
+        x, h = ops.add_drop_ln(x, self.ca(h, memory, training, l.multihead_attn.dropout), l.norm3, l.dropout2.p, training)
+        h = ops.ffn(h.reshape(B * L, d), self.ff1, self.ff2, l.dropout.p, training)
+        x, _ = ops.add_drop_ln(x, h.view(B, L, d), None, l.dropout3.p, training)
+        return x

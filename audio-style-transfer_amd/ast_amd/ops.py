@@ -313,6 +313,76 @@ class LinearFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class FFNFn(torch.autograd.Function):
+    """linear2(dropout(relu(linear1(x)))) on <= 64 token rows in two launches forward and two backward
+    (transformer.py _ff_block as style_encoder.py:181-187 / new_decoder.py:111-118 use it): the dropout mask is
+    drawn in linear1's epilogue and stored combined with the ReLU mask; backward applies it in the epilogue of
+    dh = dy W2.  Weight gradients go to the bank's batched launch."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, pw1: PackedWeight, pw2: PackedWeight, p):
+        x = x.contiguous()
+        rows = x.shape[0]
+        h = torch.empty((rows, pw1.Cop), dtype=x.dtype, device=x.device)
+        y = torch.empty((rows, pw2.Cop), dtype=x.dtype, device=x.device)
+        mask, seed, ctr = None, 0, None
+        if p > 0.0:
+            if _DropState.counter is None or _DropState.counter.device != x.device:
+                _DropState.counter = torch.zeros(1, dtype=torch.int64, device=x.device)
+            _DropState.calls += 1
+            seed, ctr = _DropState.seed + 7919 * _DropState.calls, _DropState.counter
+            mask = torch.empty_like(h)
+        check(lib().ast_skinny_gemm_ex(ptr(x), pw1.weight.data_ptr() + 4 * pw1.w_off, pw1.bias.data_ptr() + 4 * pw1.b_off, ptr(h), rows,
+                                       pw1.Co, pw1.Ci, pw1.s_co, pw1.Cop, 1, None, ptr(mask), float(p), seed, ptr(ctr), stream()),
+              "ast_skinny_gemm_ex")
+        check(lib().ast_skinny_gemm(ptr(h), pw2.weight.data_ptr() + 4 * pw2.w_off, pw2.bias.data_ptr() + 4 * pw2.b_off, ptr(y), rows,
+                                    pw2.Co, pw2.Ci, pw2.s_co, pw2.Cop, 0, stream()), "ast_skinny_gemm")
+        ctx.save_for_backward(x, h, mask)
+        ctx.pw1, ctx.pw2 = pw1, pw2
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, mask = ctx.saved_tensors
+        pw1, pw2 = ctx.pw1, ctx.pw2
+        dy = dy.contiguous()
+        rows = x.shape[0]
+        pw2.bank.defer_linear_wgrad(pw2, dy, h)
+        dh = torch.empty_like(h)
+        if mask is None:                       # eval-mode autograd: ReLU mask only
+            check(lib().ast_skinny_gemm(ptr(dy), ptr(pw2.wb), None, ptr(dh), rows, pw2.Ci, pw2.Cop, pw2.Cop, pw2.Cip, 0, stream()),
+                  "ast_skinny_gemm")
+            dz = torch.empty_like(dh)
+            check(lib().ast_relu_bwd(ptr(dh), ptr(h), ptr(dz), dh.numel(), dcode(dh.dtype), stream()), "ast_relu_bwd")
+            dh = dz
+        else:
+            check(lib().ast_skinny_gemm_ex(ptr(dy), ptr(pw2.wb), None, ptr(dh), rows, pw2.Ci, pw2.Cop, pw2.Cop, pw2.Cip, 0, ptr(mask), None,
+                                           0.0, 0, None, stream()), "ast_skinny_gemm_ex")
+        pw1.bank.defer_linear_wgrad(pw1, dh, x)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib().ast_skinny_gemm(ptr(dh), ptr(pw1.wb), None, ptr(dx), rows, pw1.Ci, pw1.Cop, pw1.Cop, pw1.Cip, 0, stream()),
+                  "ast_skinny_gemm")
+        return dx, None, None, None, None, None
+
+
+def _skinny_ok(pw, rows):
+    return (rows <= SKINNY_MAX_ROWS and pw.KK == 1 and pw.u is None and pw.Ci == pw.Cip and pw.Co == pw.Cop and pw.bank is not None
+            and pw.bias is not None)
+
+
+def ffn(x2d, pw1, pw2, p, training):
+    """linear2(dropout(relu(linear1(x2d))))."""
+    rows = x2d.shape[0]
+    if _skinny_ok(pw1, rows) and _skinny_ok(pw2, rows) and x2d.dtype == torch.float32:
+        return FFNFn.apply(x2d, pw1.weight, pw2.weight, pw1, pw2, float(p) if training else 0.0)
+    h = dropout(LinearFn.apply(x2d, pw1.weight, pw1, True), p, training)
+    h = h if pw1.Cop == pw1.Co else h[:, :pw1.Co]
+    y = LinearFn.apply(h, pw2.weight, pw2, False)
+    return y if pw2.Cop == pw2.Co else y[:, :pw2.Co]
+
+
 # ---------------------------------------------------------------------------
 # normalisation
 # ---------------------------------------------------------------------------
@@ -460,6 +530,73 @@ class LayerNormFn(torch.autograd.Function):
                                       ptr(acc_grad(ctx.gamma)), ptr(acc_grad(ctx.beta)), rows, D, dcode(x2.dtype),
                                       stream()), "ast_layernorm_bwd")
         return dx.view(ctx.shape), None, None, None
+
+
+class AddDropLNFn(torch.autograd.Function):
+    """One launch for `norm(x + dropout(sub))` on f32 token rows (ast_add_drop_ln_fwd/bwd).
+
+    Returns (s, y) with s = x + dropout(sub) and y = LayerNorm(s); with `ln` None only s.  The post-norm encoder
+    layer (style_encoder.py:181-187) uses y, the pre-norm decoder layer (new_decoder.py:111-118) carries s on as its
+    residual stream and feeds y to the next sub-layer.  gamma/beta gradients are accumulated in place."""
+
+    @staticmethod
+    def forward(ctx, x, sub, ln, p):
+        ctx.set_materialize_grads(False)
+        shape = sub.shape
+        D = shape[-1]
+        sub2 = sub.contiguous().view(-1, D)
+        x2 = x.contiguous().view(-1, D) if x is not None else None
+        rows = sub2.shape[0]
+        s = torch.empty_like(sub2)
+        mask = torch.empty_like(sub2) if p > 0.0 else None
+        seed = 0
+        if p > 0.0:
+            if _DropState.counter is None or _DropState.counter.device != sub.device:
+                _DropState.counter = torch.zeros(1, dtype=torch.int64, device=sub.device)
+            _DropState.calls += 1
+            seed = _DropState.seed + 7919 * _DropState.calls
+        y = mean = rstd = None
+        if ln is not None:
+            y = torch.empty_like(sub2)
+            mean = torch.empty(rows, dtype=torch.float32, device=sub.device)
+            rstd = torch.empty_like(mean)
+        check(lib().ast_add_drop_ln_fwd(ptr(x2), ptr(sub2), ptr(mask), ptr(s), ptr(ln.weight) if ln is not None else None,
+                                        ptr(ln.bias) if ln is not None else None, ptr(y), ptr(mean), ptr(rstd), rows, D,
+                                        float(ln.eps) if ln is not None else 0.0, float(p), seed,
+                                        ptr(_DropState.counter) if p > 0.0 else None, stream()), "ast_add_drop_ln_fwd")
+        ctx.save_for_backward(s, mean, rstd, mask)
+        ctx.ln, ctx.shape, ctx.has_x = ln, shape, x is not None
+        if ln is None:
+            return s.view(shape)
+        return s.view(shape), y.view(shape)
+
+    @staticmethod
+    def backward(ctx, ds_ext, dy=None):
+        s, mean, rstd, mask = ctx.saved_tensors
+        rows, D = s.shape
+        if ds_ext is None and dy is None:
+            return None, None, None, None
+        ds2 = ds_ext.contiguous().view(rows, D) if ds_ext is not None else None
+        dy2 = dy.contiguous().view(rows, D) if dy is not None else None
+        want_dx = ctx.has_x and ctx.needs_input_grad[0]
+        # without a LayerNorm term the residual gradient passes straight through
+        dx = None if (not want_dx or dy2 is None) else torch.empty_like(s)
+        if dy2 is None and mask is None:
+            return (ds_ext if want_dx else None), ds_ext, None, None
+        dsub = torch.empty_like(s)
+        ln = ctx.ln
+        check(lib().ast_add_drop_ln_bwd(ptr(dy2), ptr(ds2), ptr(s), ptr(ln.weight) if dy2 is not None else None, ptr(mean), ptr(rstd),
+                                        ptr(mask), ptr(dx), ptr(dsub), ptr(acc_grad(ln.weight)) if dy2 is not None else None,
+                                        ptr(acc_grad(ln.bias)) if dy2 is not None else None, rows, D, stream()), "ast_add_drop_ln_bwd")
+        if want_dx and dx is None:
+            dx = ds2
+        return (dx.view(ctx.shape) if want_dx else None), dsub.view(ctx.shape), None, None
+
+
+def add_drop_ln(x, sub, ln, p, training):
+    """(s, y) = (x + dropout(sub), LayerNorm(s)); y is None when ln is None."""
+    out = AddDropLNFn.apply(x, sub, ln, float(p) if training else 0.0)
+    return (out, None) if ln is None else out
 
 
 # ---------------------------------------------------------------------------

@@ -64,6 +64,15 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// splitmix64 finaliser: the dropout masks are mix64(base + element index), base = f(seed, device step counter)
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+}
+__device__ __forceinline__ float dropout_keep(uint64_t base, uint64_t i, float p, float keep) {
+  const uint32_t r = (uint32_t)(mix64(base + i) >> 40);             // 24 random bits
+  return ((float)r * (1.f / 16777216.f)) >= p ? keep : 0.f;
+}
+
 // block-wide sum for blockDim.x = multiple of 64 (<= 1024); all threads get the result
 __device__ __forceinline__ float block_sum(float v, float* red /* >= 17 floats of LDS */) {
   v = wave_sum(v);

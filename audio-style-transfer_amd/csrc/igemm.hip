@@ -812,7 +812,8 @@ IgemmPlan plan_igemm(const ast_gather_t& g, int M, int dtype) {
   p.kgroups = 1;
   // under-filled grid with a long K loop: split K inside the workgroup (sweep: b5 35 -> 24 us, b4 47 -> 41 us; b3, with
   // 684 tiles, loses)
-  if (p.bm == 64 && p.bn == 64 && blocks < 400 && KT >= 16) { p.kgroups = 4; p.kch = 4; }
+  static const long kg_blocks = getenv("AST_IGEMM_KG_BLOCKS") ? atol(getenv("AST_IGEMM_KG_BLOCKS")) : 400;
+  if (p.bm == 64 && p.bn == 64 && blocks < kg_blocks && KT >= 16) { p.kgroups = 4; p.kch = 4; }
   else if (blocks < 200 && KT >= 16 && (long)M * g.Cd <= (1L << 20)) p.nsplit = blocks < 120 ? 4 : 2;
   p.depth = 2;                                          // depth 4 measured no better (the loop is not latency-bound)
   if (const char* f = getenv("AST_IGEMM_FORCE")) {      // tuning aid: "bm,bn,kch,nsplit[,kgroups]"

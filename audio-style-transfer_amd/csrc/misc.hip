@@ -278,15 +278,11 @@ __global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__
     unsafeAtomicAdd(out + threadIdx.x, t);
   }
 }
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
-}
 __global__ void dropout_mask_kernel(float* __restrict__ mask, size_t n, float p, uint64_t seed, const int64_t* __restrict__ d_offset) {
   const uint64_t base = mix64(seed ^ mix64((uint64_t)(d_offset ? *d_offset : 0)));
   const float keep = 1.f / (1.f - p);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const uint32_t r = (uint32_t)(mix64(base + i) >> 40);           // 24 random bits
-    mask[i] = ((float)r * (1.f / 16777216.f)) >= p ? keep : 0.f;
+    mask[i] = dropout_keep(base, i, p, keep);
   }
 }
 
@@ -295,8 +291,7 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restric
   const uint64_t base = mix64(seed ^ mix64((uint64_t)(d_offset ? *d_offset : 0)));
   const float keep = 1.f / (1.f - p);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const uint32_t r = (uint32_t)(mix64(base + i) >> 40);
-    const float m = ((float)r * (1.f / 16777216.f)) >= p ? keep : 0.f;
+    const float m = dropout_keep(base, i, p, keep);
     mask[i] = m;
     y[i] = x[i] * m;
   }

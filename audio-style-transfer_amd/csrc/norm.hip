@@ -279,6 +279,68 @@ __global__ void layernorm_bwd_kernel(const float* __restrict__ dy, const float* 
   }
 }
 
+
+// ---- fused residual + dropout + LayerNorm (token rows, f32), one wave per row -------------------------------
+//   s = x + dropout(sub)        (x may be null: s = dropout(sub);  p == 0: no mask is written)
+//   y = LayerNorm(s)            (gamma null: no normalisation, s is the only output)
+// s is always written: it is the residual stream the pre-norm decoder carries on and the LN input its backward needs.
+__global__ void add_drop_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ sub, float* __restrict__ mask,
+                                       float* __restrict__ s_out, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int rows, int D,
+                                       float eps, float p, uint64_t seed, const int64_t* __restrict__ d_offset) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const size_t o = (size_t)row * D;
+  const uint64_t base = p > 0.f ? mix64(seed ^ mix64((uint64_t)(d_offset ? *d_offset : 0))) : 0;
+  const float keep = 1.f / (1.f - p);
+  float acc = 0.f;
+  for (int i = lane; i < D; i += 64) {
+    float v = sub[o + i];
+    if (p > 0.f) { const float m = dropout_keep(base, o + i, p, keep); mask[o + i] = m; v *= m; }
+    if (x) v += x[o + i];
+    s_out[o + i] = v;
+    acc += v;
+  }
+  if (!gamma) return;
+  const float m = wave_sum(acc) / D;
+  float q = 0.f;
+  for (int i = lane; i < D; i += 64) { const float d = s_out[o + i] - m; q += d * d; }      // own stores: visible to this lane
+  const float r = rsqrtf(wave_sum(q) / D + eps);
+  for (int i = lane; i < D; i += 64) y[o + i] = (s_out[o + i] - m) * r * gamma[i] + beta[i];
+  if (lane == 0) { mean[row] = m; rstd[row] = r; }
+}
+
+//   ds = ds_ext + LayerNorm_bwd(dy; s)     (either term may be absent)
+//   dx = ds,  dsub = ds * mask             (dx may alias nothing; both are plain stores)
+__global__ void add_drop_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ds_ext, const float* __restrict__ s,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                       const float* __restrict__ mask, float* __restrict__ dx, float* __restrict__ dsub,
+                                       float* dgamma, float* dbeta, int rows, int D) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const size_t o = (size_t)row * D;
+  float a = 0.f, b = 0.f, m = 0.f, r = 0.f;
+  if (dy) {
+    m = mean[row]; r = rstd[row];
+    for (int i = lane; i < D; i += 64) {
+      const float xh = (s[o + i] - m) * r, g = dy[o + i] * gamma[i];
+      a += g; b += g * xh;
+    }
+    a = wave_sum(a) / D; b = wave_sum(b) / D;
+  }
+  for (int i = lane; i < D; i += 64) {
+    float d = ds_ext ? ds_ext[o + i] : 0.f;
+    if (dy) {
+      const float xh = (s[o + i] - m) * r, g = dy[o + i] * gamma[i];
+      d += r * (g - a - xh * b);
+      if (dgamma) unsafeAtomicAdd(dgamma + i, dy[o + i] * xh);
+      if (dbeta) unsafeAtomicAdd(dbeta + i, dy[o + i]);
+    }
+    if (dx) dx[o + i] = d;
+    dsub[o + i] = mask ? d * mask[o + i] : d;
+  }
+}
+
 int grid_for(size_t n, int block = 256) { return (int)std::min<size_t>((n + block - 1) / block, 256 * 16); }
 
 }  // namespace
@@ -378,6 +440,29 @@ extern "C" int ast_layernorm_bwd(const void* dy, const void* x, const float* gam
   if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || D <= 0) AST_FAIL("ast_layernorm_bwd: bad args");
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
                      (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, rows, D);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_add_drop_ln_fwd(const float* x, const float* sub, float* mask, float* s_out, const float* gamma, const float* beta,
+                                   float* y, float* mean, float* rstd, int rows, int D, float eps, float p, uint64_t seed,
+                                   const int64_t* d_offset, void* stream) {
+  if (!sub || !s_out || rows <= 0 || D <= 0 || p < 0.f || p >= 1.f) AST_FAIL("ast_add_drop_ln_fwd: bad args");
+  if (p > 0.f && !mask) AST_FAIL("ast_add_drop_ln_fwd: dropout needs a mask buffer");
+  if (gamma && (!beta || !y || !mean || !rstd)) AST_FAIL("ast_add_drop_ln_fwd: LayerNorm outputs missing");
+  hipLaunchKernelGGL(add_drop_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, sub, mask, s_out, gamma, beta,
+                     y, mean, rstd, rows, D, eps, p, seed, d_offset);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_add_drop_ln_bwd(const float* dy, const float* ds_ext, const float* s, const float* gamma, const float* mean,
+                                   const float* rstd, const float* mask, float* dx, float* dsub, float* dgamma, float* dbeta, int rows,
+                                   int D, void* stream) {
+  if ((!dy && !ds_ext) || !dsub || rows <= 0 || D <= 0) AST_FAIL("ast_add_drop_ln_bwd: bad args");
+  if (dy && (!s || !gamma || !mean || !rstd)) AST_FAIL("ast_add_drop_ln_bwd: LayerNorm state missing");
+  hipLaunchKernelGGL(add_drop_ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, ds_ext, s, gamma, mean, rstd,
+                     mask, dx, dsub, dgamma, dbeta, rows, D);
   AST_CHECK_LAUNCH();
   return 0;
 }

@@ -18,7 +18,9 @@ namespace {
 template <int NS>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int M, int N,
-                                                           int K, int ldx, int ldw, int ldy, int relu) {
+                                                           int K, int ldx, int ldw, int ldy, int relu,
+                                                           const float* __restrict__ mul_mask, float* __restrict__ drop_mask,
+                                                           float p, uint64_t seed, const int64_t* __restrict__ d_offset) {
   __shared__ f32x4 part[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -52,12 +54,25 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
   for (int q = 1; q < 4; ++q) { const f32x4 t = part[q][lane]; r[0] += t[0]; r[1] += t[1]; r[2] += t[2]; r[3] += t[3]; }
   const int m = m0 + i, nb = n0 + 4 * g;              // D[row = 4 g + r (n)][col = i (m)]
   if (m >= M) return;
+  // optional epilogues of the fused FFN: drop_mask != null draws the dropout mask here and stores the COMBINED
+  // mask (0 where ReLU or dropout zeroed the unit, else 1/(1-p)) for the backward pass; mul_mask != null applies
+  // such a mask to the result (the backward's dh = (dy W2) * mask)
+  const uint64_t base = drop_mask ? mix64(seed ^ mix64((uint64_t)(d_offset ? *d_offset : 0))) : 0;
+  const float keep = 1.f / (1.f - p);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int n = nb + q;
     if (n < N) {
+      const size_t o = (size_t)m * ldy + n;
       float v = r[q] + (bias ? bias[n] : 0.f);
-      y[(size_t)m * ldy + n] = relu ? fmaxf(v, 0.f) : v;
+      if (relu) v = fmaxf(v, 0.f);
+      if (drop_mask) {
+        const float km = dropout_keep(base, o, p, keep);
+        drop_mask[o] = (relu && v <= 0.f) ? 0.f : km;
+        v *= km;
+      }
+      if (mul_mask) v *= mul_mask[o];
+      y[o] = v;
     }
   }
 }
@@ -182,20 +197,30 @@ extern "C" int ast_linear_wgrad_batched(const void* table, int count, int max_ti
   return 0;
 }
 
-extern "C" int ast_skinny_gemm(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldw, int ldy,
-                               int relu, void* stream) {
+extern "C" int ast_skinny_gemm_ex(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldw, int ldy,
+                                  int relu, const float* mul_mask, float* drop_mask, float p, uint64_t seed, const int64_t* d_offset,
+                                  void* stream) {
   if (!x || !w || !y || M < 1 || M > 64 || N < 1 || K < 4 || (K & 3) || (ldw & 3)) AST_FAIL("ast_skinny_gemm: bad args M=%d N=%d K=%d", M, N, K);
   if ((((uintptr_t)x) | ((uintptr_t)w)) & 15) AST_FAIL("ast_skinny_gemm: operands must be 16-byte aligned");
+  if (drop_mask && (p <= 0.f || p >= 1.f)) AST_FAIL("ast_skinny_gemm: dropout epilogue needs 0 < p < 1");
   const int steps = (K + 63) / 64;                    // 16-wide K steps per wave (4 waves split K)
   dim3 grid((N + 15) / 16, (M + 15) / 16);
   hipStream_t s = (hipStream_t)stream;
-  if (steps <= 2) hipLaunchKernelGGL(skinny_gemm_kernel<2>, grid, dim3(256), 0, s, x, w, bias, y, M, N, K, K, ldw, ldy, relu);
-  else if (steps <= 4) hipLaunchKernelGGL(skinny_gemm_kernel<4>, grid, dim3(256), 0, s, x, w, bias, y, M, N, K, K, ldw, ldy, relu);
-  else if (steps <= 8) hipLaunchKernelGGL(skinny_gemm_kernel<8>, grid, dim3(256), 0, s, x, w, bias, y, M, N, K, K, ldw, ldy, relu);
-  else if (steps <= 16) hipLaunchKernelGGL(skinny_gemm_kernel<16>, grid, dim3(256), 0, s, x, w, bias, y, M, N, K, K, ldw, ldy, relu);
+#define AST_SK(NS_) hipLaunchKernelGGL(skinny_gemm_kernel<NS_>, grid, dim3(256), 0, s, x, w, bias, y, M, N, K, K, ldw, ldy, relu, mul_mask, \
+                                       drop_mask, p, seed, d_offset)
+  if (steps <= 2) AST_SK(2);
+  else if (steps <= 4) AST_SK(4);
+  else if (steps <= 8) AST_SK(8);
+  else if (steps <= 16) AST_SK(16);
   else AST_FAIL("ast_skinny_gemm: K=%d too large for the token path (<= 1024)", K);
+#undef AST_SK
   AST_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int ast_skinny_gemm(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldw, int ldy,
+                               int relu, void* stream) {
+  return ast_skinny_gemm_ex(x, w, bias, y, M, N, K, ldw, ldy, relu, nullptr, nullptr, 0.f, 0, nullptr, stream);
 }
 
 extern "C" int ast_linear_wgrad(const float* dy, const float* x, float* dW, float* db, int M, int N, int K, int lddy, int ldw,

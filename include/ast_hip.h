@@ -74,6 +74,13 @@ int ast_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t* g,
  * of in_proj_weight or the transposed pack for the data gradient).  One wave per output column. */
 int ast_skinny_gemm(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldw,
                     int ldy, int relu, void* stream);
+/* ast_skinny_gemm with the fused-FFN epilogues (TransformerEncoderLayer/DecoderLayer._ff_block,
+ * linear2(dropout(relu(linear1(x))))):  drop_mask != NULL draws a dropout mask (p, seed, d_offset as ast_dropout_fwd),
+ * applies it and stores the COMBINED relu+dropout mask (0 or 1/(1-p)); mul_mask != NULL multiplies the result by a
+ * stored mask (the backward's dh = (dy W2) * mask). */
+int ast_skinny_gemm_ex(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldw, int ldy,
+                       int relu, const float* mul_mask, float* drop_mask, float p, uint64_t seed, const int64_t* d_offset,
+                       void* stream);
 /* dW[n][k] += sum_m dy[m][n] x[m][k]; db[n] += sum_m dy[m][n]  -- straight into the parameter gradients */
 int ast_linear_wgrad(const float* dy, const float* x, float* dW, float* db, int M, int N, int K, int lddy, int ldw,
                      void* stream);
@@ -159,6 +166,20 @@ int ast_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
 int ast_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                       const float* rstd, void* dx, float* dgamma, float* dbeta, int rows, int D,
                       int dtype, void* stream);
+
+/* Fused residual + dropout + LayerNorm on f32 token rows (one launch for `norm(x + dropout(sub))`,
+ * torch/nn/modules/transformer.py's post-norm and pre-norm blocks as style_encoder.py:181-187 and
+ * new_decoder.py:111-118 instantiate them):
+ *   s = x + dropout_p(sub)   (x NULL: s = dropout(sub); p == 0: mask untouched)
+ *   y = LayerNorm(s)         (gamma NULL: s only)
+ * mask holds 0 or 1/(1-p); seed/d_offset as ast_dropout_fwd.  Backward:
+ *   ds = ds_ext + LN'(dy; s);  dx = ds (dx may be NULL);  dsub = ds * mask (mask NULL: ds). */
+int ast_add_drop_ln_fwd(const float* x, const float* sub, float* mask, float* s_out, const float* gamma, const float* beta,
+                        float* y, float* mean, float* rstd, int rows, int D, float eps, float p, uint64_t seed,
+                        const int64_t* d_offset, void* stream);
+int ast_add_drop_ln_bwd(const float* dy, const float* ds_ext, const float* s, const float* gamma, const float* mean,
+                        const float* rstd, const float* mask, float* dx, float* dsub, float* dgamma, float* dbeta, int rows,
+                        int D, void* stream);
 
 /* ---- pooling / resampling ---------------------------------------------------- */
 /* nn.AdaptiveAvgPool2d with bins [floor(i*In/Out), ceil((i+1)*In/Out)) (style_encoder.py:113-114, new_decoder.py:51) */

@@ -51,6 +51,24 @@ def make_bank(mods, kinds, dtype):
     return bank, pws
 
 
+def host_dropout_mask(seed, counter, n, p):
+    """csrc/ast_common.h dropout_keep on the host: mix64(base + i) >> 40 against p, base = mix64(seed ^ mix64(counter))."""
+    M = (1 << 64) - 1
+
+    def mix(z):
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+    base = mix(seed ^ mix(counter))
+    keep = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    out = np.empty(n, dtype=np.float32)
+    for i in range(n):
+        r = mix((base + i) & M) >> 40
+        out[i] = keep if np.float32(r) * np.float32(1.0 / 16777216.0) >= np.float32(p) else 0.0
+    return torch.from_numpy(out)
+
+
 def sn_reference_weight(m, dim):
     """one power iteration + sigma, on a CPU copy of the buffers (oracle.spectral_weight)."""
     sd = {"weight_orig": m.weight_orig.detach().cpu().clone().requires_grad_(True),
@@ -259,6 +277,87 @@ def test_layernorm():
     assert rel_err(y, yr) < 1e-5
     y.backward(gy.to(DEV))
     assert rel_err(xh.grad, xr.grad) < 1e-4 and rel_err(ln.weight.grad, wr.grad) < 1e-4 and rel_err(ln.bias.grad, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("rows", [6, 24])
+def test_ffn_fused(rows):
+    """FFNFn = linear2(dropout(relu(linear1(x)))): exact against torch at p = 0; at p > 0 the mask is replayed
+    (same call index) so the op is a fixed piecewise-linear map and <g, J v> is checked by central differences."""
+    torch.manual_seed(21)
+    l1, l2 = nn.Linear(256, 1024).to(DEV), nn.Linear(1024, 256).to(DEV)
+    bank, (pw1, pw2) = make_bank([l1, l2], ["linear", "linear"], torch.float32)
+    bank.prepare(True)
+    x = torch.randn(rows, 256)
+    xr = x.clone().requires_grad_(True)
+    w1, b1, w2, b2 = [t.detach().cpu().clone().requires_grad_(True) for t in (l1.weight, l1.bias, l2.weight, l2.bias)]
+    yr = F.linear(torch.relu(F.linear(xr, w1, b1)), w2, b2)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    xh = x.to(DEV).requires_grad_(True)
+    y = ops.ffn(xh, pw1, pw2, 0.1, training=False)
+    assert rel_err(y, yr) < 2e-4
+    y.backward(gy.to(DEV))
+    bank._flush()
+    assert rel_err(xh.grad, xr.grad) < 2e-4
+    for got, ref in ((l1.weight.grad, w1.grad), (l1.bias.grad, b1.grad), (l2.weight.grad, w2.grad), (l2.bias.grad, b2.grad)):
+        assert rel_err(got, ref) < 2e-4
+    # dropout on: the mask is a pure function of (seed, step counter, element index) - rebuild it on the host
+    ops._DropState.calls = 1000
+    for m in (l1, l2):
+        m.zero_grad()
+    xh = x.to(DEV).requires_grad_(True)
+    y1 = ops.ffn(xh, pw1, pw2, 0.25, training=True)
+    mask = host_dropout_mask(ops._DropState.seed + 7919 * 1001, int(ops._DropState.counter.item()), rows * 1024, 0.25).view(rows, 1024)
+    assert 0.7 < float((mask > 0).float().mean()) < 0.8
+    xr = x.clone().requires_grad_(True)
+    w1, b1, w2, b2 = [t.detach().cpu().clone().requires_grad_(True) for t in (l1.weight, l1.bias, l2.weight, l2.bias)]
+    yr = F.linear(torch.relu(F.linear(xr, w1, b1)) * mask, w2, b2)
+    yr.backward(gy)
+    assert rel_err(y1, yr) < 2e-4
+    y1.backward(gy.to(DEV))
+    assert rel_err(xh.grad, xr.grad) < 2e-4
+    for got, ref in ((l1.weight.grad, w1.grad), (l1.bias.grad, b1.grad), (l2.weight.grad, w2.grad), (l2.bias.grad, b2.grad)):
+        assert rel_err(got, ref) < 2e-4
+
+
+@pytest.mark.parametrize("with_ln,use_s,use_y", [(True, False, True), (True, True, True), (False, True, False)])
+def test_add_dropout_layernorm_fused(with_ln, use_s, use_y):
+    """ast_add_drop_ln: (s, y) = (x + dropout(sub), LN(s)) against torch with the kernel's own mask replayed."""
+    torch.manual_seed(17)
+    ln = nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_(0, 0.2)
+    x, sub = torch.randn(3, 5, 256), torch.randn(3, 5, 256) * 1.5
+    for p in (0.0, 0.3):
+        ln.zero_grad()
+        xh, sh = x.to(DEV).requires_grad_(True), sub.to(DEV).requires_grad_(True)
+        s, y = ops.add_drop_ln(xh, sh, ln if with_ln else None, p, True)
+        mask = ((s.detach() - xh.detach()) / sh.detach()).cpu()            # 0 or 1/(1-p)
+        if p == 0.0:
+            assert torch.allclose(mask, torch.ones_like(mask), atol=1e-5)
+        else:
+            keep = 1.0 / (1.0 - p)
+            assert bool((((mask.abs() < 1e-4) | ((mask - keep).abs() < 1e-3))).all())
+            assert 0.6 < float((mask > 0.5).float().mean()) < 0.8
+            mask = torch.where(mask > 0.5, torch.full_like(mask, keep), torch.zeros_like(mask))
+        xr, sr = x.clone().requires_grad_(True), sub.clone().requires_grad_(True)
+        wr, br = ln.weight.detach().cpu().clone().requires_grad_(True), ln.bias.detach().cpu().clone().requires_grad_(True)
+        s_ref = xr + sr * mask
+        y_ref = F.layer_norm(s_ref, (256,), wr, br) if with_ln else None
+        gs, gy = torch.randn(3, 5, 256), torch.randn(3, 5, 256)
+        loss = 0.0
+        loss_ref = 0.0
+        if use_s:
+            loss = loss + (s * gs.to(DEV)).sum(); loss_ref = loss_ref + (s_ref * gs).sum()
+        if use_y:
+            loss = loss + (y * gy.to(DEV)).sum(); loss_ref = loss_ref + (y_ref * gy).sum()
+        loss.backward(); loss_ref.backward()
+        assert rel_err(s, s_ref) < 1e-5
+        if with_ln:
+            assert rel_err(y, y_ref) < 1e-5
+        assert rel_err(xh.grad, xr.grad) < 1e-4 and rel_err(sh.grad, sr.grad) < 1e-4, (p, with_ln, use_s, use_y)
+        if use_y:
+            assert rel_err(ln.weight.grad, wr.grad) < 1e-4 and rel_err(ln.bias.grad, br.grad) < 1e-4
 
 
 @pytest.mark.parametrize("cross,causal,Lq,Lk", [(False, False, 3, 3), (False, True, 4, 4), (True, False, 2, 4), (False, False, 5, 5)])
