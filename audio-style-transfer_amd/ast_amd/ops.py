@@ -407,6 +407,43 @@ def _stats(x):
     return sums
 
 
+class _SyncBN:
+    """Cross-rank BatchNorm statistics: with world > 1 the per-image sums of every BatchNorm2d are
+    all-reduced before the finalize, forward and backward, so the normalisation is over all B*S images of the global
+    batch as in the single-process reference.  Eager mode only (a collective per BN layer cannot sit inside the
+    captured step); the default data-parallel mode keeps per-rank statistics."""
+    world = 1
+    group = None
+
+
+def set_sync_bn(world=1, group=None):
+    _SyncBN.world, _SyncBN.group = int(world), group
+
+
+def _global_sums(sums, n_floats):
+    """all-reduced copy of the first n_floats of a statistics scratch; the scratch itself is handed back zeroed."""
+    import torch.distributed as dist
+    g = sums[:n_floats].clone()
+    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=_SyncBN.group)
+    return g
+
+
+def _bn_batch_stats(x, gamma, beta, bn):
+    """(mean, rstd, scale, shift) of a training-mode BatchNorm2d over the local or (sync-BN) global batch."""
+    N, H, W, C = x.shape
+    sums = _stats(x)
+    if _SyncBN.world > 1:
+        g = _global_sums(sums, N * C * 2)
+        sums[:N * C * 2].zero_()
+        out = torch.empty((4, C), dtype=torch.float32, device=x.device)
+        check(lib().ast_norm_finalize(ptr(g), 0, ptr(bn.num_batches_tracked), N, H * W * _SyncBN.world, C, gamma.numel(), 0, ptr(gamma),
+                                      ptr(beta), ptr(bn.running_mean), ptr(bn.running_var), 0, bn.eps, ptr(out[0]), ptr(out[1]),
+                                      ptr(out[2]), ptr(out[3]), stream()), "ast_norm_finalize")
+        return out[0], out[1], out[2], out[3]
+    return _finalize(sums, N, H * W, C, gamma.numel(), False, gamma, beta, bn.running_mean, bn.running_var, False, bn.eps, x.device,
+                     nbt=bn.num_batches_tracked)
+
+
 def _finalize(sums, N, HW, C, Creal, instance, gamma, beta, rm, rv, eval_mode, eps, dev, nbt=None):
     n = N * C if instance else C
     out = torch.empty((4, n), dtype=torch.float32, device=dev)
@@ -425,9 +462,7 @@ class BatchNormActFn(torch.autograd.Function):
         N, H, W, C = x.shape
         Creal = gamma.numel()
         if training:
-            sums = _stats(x)
-            mean, rstd, scale, shift = _finalize(sums, N, H * W, C, Creal, False, gamma, beta, bn.running_mean,
-                                                 bn.running_var, False, bn.eps, x.device, nbt=bn.num_batches_tracked)
+            mean, rstd, scale, shift = _bn_batch_stats(x, gamma, beta, bn)
         else:
             mean, rstd, scale, shift = _finalize(None, N, H * W, C, Creal, False, gamma, beta, bn.running_mean,
                                                  bn.running_var, True, bn.eps, x.device)
@@ -450,9 +485,14 @@ class BatchNormActFn(torch.autograd.Function):
         check(lib().ast_norm_bwd_sums(ptr(dy), ptr(y), ptr(x), None, ptr(sums3), N, H * W, C, int(ctx.relu),
                                       dcode(x.dtype), 1, stream()), "ast_norm_bwd_sums")
         k1 = torch.empty((C, 3), dtype=torch.float32, device=x.device)
+        gsum = _global_sums(sums3, N * C * 3) if _SyncBN.world > 1 else None
+        # gamma/beta gradients come from the LOCAL sums (the gradient all-reduce averages them over ranks)
         check(lib().ast_norm_bwd_finalize(ptr(sums3), 1, N, H * W, C, gamma.numel(), ptr(gamma), ptr(mean), ptr(rstd),
                                           ptr(acc_grad(gamma)), ptr(acc_grad(beta)), ptr(k1),
                                           None, None, None, None, None, None, stream()), "ast_norm_bwd_finalize")
+        if gsum is not None:        # dx coefficients from the global sums and the global pixel count
+            check(lib().ast_norm_bwd_finalize(ptr(gsum), 0, N, H * W * _SyncBN.world, C, gamma.numel(), ptr(gamma), ptr(mean), ptr(rstd),
+                                              None, None, ptr(k1), None, None, None, None, None, None, stream()), "ast_norm_bwd_finalize")
         dx = torch.empty_like(x)
         check(lib().ast_norm_bwd_apply(ptr(dy), ptr(y), ptr(x), None, ptr(k1), None, ptr(dx), None, N, H * W, C,
                                        int(ctx.relu), dcode(x.dtype), stream()), "ast_norm_bwd_apply")
@@ -468,8 +508,7 @@ class ResTailFn(torch.autograd.Function):
         N, H, W, C = c2.shape
         Creal = g1.numel()
         if training:
-            m1, r1, s1, f1 = _finalize(_stats(c2), N, H * W, C, Creal, False, g1, b1, bn.running_mean, bn.running_var,
-                                       False, bn.eps, c2.device, nbt=bn.num_batches_tracked)
+            m1, r1, s1, f1 = _bn_batch_stats(c2, g1, b1, bn)
         else:
             m1, r1, s1, f1 = _finalize(None, N, H * W, C, Creal, False, g1, b1, bn.running_mean, bn.running_var,
                                        True, bn.eps, c2.device)
@@ -495,10 +534,14 @@ class ResTailFn(torch.autograd.Function):
                                       1, stream()), "ast_norm_bwd_sums")
         k1 = torch.empty((C, 3), dtype=torch.float32, device=dev)
         k2 = torch.empty((N, C, 3), dtype=torch.float32, device=dev)
+        gsum = _global_sums(sums3, N * C * 3) if _SyncBN.world > 1 else None
         check(lib().ast_norm_bwd_finalize(ptr(sums3), 1, N, H * W, C, g1.numel(), ptr(g1), ptr(m1), ptr(r1),
                                           ptr(acc_grad(g1)), ptr(acc_grad(b1)), ptr(k1), ptr(g2), ptr(m2), ptr(r2),
                                           ptr(acc_grad(g2)), ptr(acc_grad(b2)), ptr(k2), stream()),
               "ast_norm_bwd_finalize")
+        if gsum is not None:        # batch branch only: the InstanceNorm shortcut is per image, hence local
+            check(lib().ast_norm_bwd_finalize(ptr(gsum), 0, N, H * W * _SyncBN.world, C, g1.numel(), ptr(g1), ptr(m1), ptr(r1),
+                                              None, None, ptr(k1), None, None, None, None, None, None, stream()), "ast_norm_bwd_finalize")
         dc2, dds = torch.empty_like(c2), torch.empty_like(ds)
         check(lib().ast_norm_bwd_apply(ptr(dy), ptr(y), ptr(c2), ptr(ds), ptr(k1), ptr(k2), ptr(dc2), ptr(dds), N, H * W,
                                        C, 1, dcode(c2.dtype), stream()), "ast_norm_bwd_apply")

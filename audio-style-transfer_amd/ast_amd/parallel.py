@@ -34,3 +34,47 @@ def max_over_ranks(value: float, device) -> float:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t)
+
+
+def global_row_order(global_batch: int, world: int):
+    """(rank, local row) of every row of the collated global batch, in global order: the inverse of balanced_shard."""
+    per = global_batch // 2 // world
+    return [(r, h * per + i) for h in (0, 1) for r in range(world) for i in range(per)]
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """All ranks' (b, ...) rows assembled into the (B, ...) global batch in the single-process row order
+    (InfoNCE, HSIC, class prototypes and the margin term depend on the whole batch).
+    Every rank then evaluates the same global loss L; with the later gradient MEAN over ranks the right
+    local gradient is the SUM over ranks of dL/d(global rows), sliced to this rank's rows."""
+
+    @staticmethod
+    def forward(ctx, x, rank, world, group):
+        order = global_row_order(x.shape[0] * world, world)
+        ctx.rank, ctx.world, ctx.group, ctx.order = rank, world, group, order
+        mine = [k for k, (r, _) in enumerate(order) if r == rank]
+        # a SUM all-reduce of rows scattered into a zero global buffer: a few KB, and (unlike all_gather on
+        # device tensors) available on both backends the tests use (nccl = RCCL, gloo)
+        out = torch.zeros((len(order),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        out[mine] = x.detach()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        mine = [k for k, (r, _) in enumerate(ctx.order) if r == ctx.rank]        # ascending local row
+        return g[mine], None, None, None
+
+
+def gather_rows(x: torch.Tensor, rank: int, world: int, group=None) -> torch.Tensor:
+    return x if world == 1 else GatherRowsFn.apply(x, rank, world, group)
+
+
+def global_labels(local_labels: torch.Tensor, world: int) -> torch.Tensor:
+    """Labels of the gathered batch.  Every rank holds the same balanced layout (balanced_shard), so the global
+    labels are the local halves repeated."""
+    b = local_labels.numel()
+    lo, hi = local_labels[:b // 2], local_labels[b // 2:]
+    return torch.cat([lo.repeat(world), hi.repeat(world)])

@@ -25,7 +25,8 @@ from .content_encoder import ContentEncoder
 from .discriminator import Discriminator
 from .losses import adversarial_loss, disentanglement_loss, infoNCE_loss, margin_loss
 from .new_decoder import Decoder, compute_comprehensive_loss
-from .style_encoder import StyleEncoder, _module_bank, initialize_weights
+from .parallel import gather_rows, global_labels
+from .style_encoder import StyleEncoder, _module_bank, class_prototypes, initialize_weights
 
 
 @dataclasses.dataclass
@@ -48,6 +49,12 @@ class TrainConfig:
     segmented: bool = False       # capture the step as 3 graphs (what world > 1 uses); for testing on one GPU
     multi_stream: bool = True     # style encoder / content encoder / decoder target-encoder on separate HIP streams
     dropout: bool = True          # nn.Dropout(0.1) as constructed by the reference
+    # world > 1 only: reproduce the single-process step on the GLOBAL batch (SURVEY 8(e)(2)+(3)): BatchNorm statistics
+    # all-reduced per layer, style/content embeddings all-gathered for InfoNCE / HSIC / class prototypes / margin.
+    # Needs a collective per BN layer, so the step runs eagerly; the default keeps per-rank statistics and losses
+    # (valid DDP, not loss-matched) and runs as three hipGraphs.
+    loss_matched: bool = False
+    keep_grads: bool = False      # eager mode: keep a copy of the (all-reduced) generator gradient for tests
 
 
 def curriculum_gates(progress: float):
@@ -121,6 +128,11 @@ class Trainer:
             m.to(self.device).train()
         self.G = FlatGroup([self.style, self.content, self.decoder], self.device)
         self.D = FlatGroup([self.disc], self.device)
+        self._matched = bool(self.cfg.loss_matched and world > 1)
+        if self._matched:
+            ops.set_sync_bn(world)
+            self.cfg = dataclasses.replace(self.cfg, use_graph=False, multi_stream=False)
+        self._glob = None
         self._graphs = {}
         self._streams = None
         self._y_emb = None
@@ -160,6 +172,13 @@ class Trainer:
                 main.wait_stream(st)
             for t in (style_emb, class_emb, content_emb, y_emb):
                 t.record_stream(main)
+        elif self._matched:
+            style_emb, _ = self.style(x, None)
+            content_emb = self.content(x)
+            style_g = gather_rows(style_emb, self.rank, self.world)
+            labels_g = global_labels(labels_host, self.world)
+            class_emb = class_prototypes(style_g, labels_g)            # prototypes over the global batch
+            self._glob = (style_g, labels_g)
         else:
             style_emb, class_emb = self.style(x, labels_host)
             content_emb = self.content(x)
@@ -181,12 +200,16 @@ class Trainer:
         total = c.w_rec * rec["total_loss"]
         parts = {"rec": rec["total_loss"].detach()}
         total = total + c.w_margin * margin_loss(class_emb)
+        style_b, labels_b, content_b = style_emb, labels_host, content_emb.mean(dim=1)
+        if self._matched:                    # batch-coupled terms on the gathered global batch
+            style_b, labels_b = self._glob
+            content_b = gather_rows(content_b, self.rank, self.world)
         if c.use_nce:
-            nce = infoNCE_loss(style_emb, labels_host)
+            nce = infoNCE_loss(style_b, labels_b)
             total = total + c.w_nce * nce
             parts["nce"] = nce.detach()
         if c.use_hsic:
-            hs = disentanglement_loss(style_emb, content_emb.mean(dim=1))
+            hs = disentanglement_loss(style_b, content_b)
             total = total + c.w_hsic * hs
             parts["hsic"] = hs.detach()
         if c.use_adv:
@@ -224,6 +247,8 @@ class Trainer:
         self.D.all_reduce(self.world)
         self._seg_b(x, labels_host)
         self.G.all_reduce(self.world)
+        if self.cfg.keep_grads:
+            self.last_grad_g = self.G.flat_g.clone()
         self._seg_c(x, labels_host)
         return self._parts
 

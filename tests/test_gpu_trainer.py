@@ -2,6 +2,7 @@
 on three concurrent streams, or as a replayed hipGraph (dropout off => deterministic up to the
 summation order of f32 atomics)."""
 import math
+import os
 
 import pytest
 import torch
@@ -72,3 +73,20 @@ def test_frontend_in_step_matches_prefilled_input():
     for k in ra:
         tol = 2e-3 if k in ("adv_g", "total") else 2e-4
         assert math.isclose(ra[k], rb[k], rel_tol=tol, abs_tol=1e-6), (k, ra[k], rb[k])
+
+
+def test_loss_matched_data_parallel_two_ranks_one_gpu():
+    """SURVEY 8(e)(2)+(3): two ranks (gloo, both on cuda:0) with sync-BN and gathered batch-coupled losses reproduce
+    the single-process step on the global batch; without them (the default graph mode's semantics) InfoNCE differs."""
+    import json, subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dp_match.py")
+    out = subprocess.run([sys.executable, tool, "--batch", "8", "--sections", "1", "--port", "29561"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = r["losses_single"], r["losses_dp"]
+    for k in a:
+        tol = 2e-3 if k in ("adv_g", "total") else 2e-4          # adv_g: behind the sign-sensitive first Adam step of D
+        assert math.isclose(a[k], b[k], rel_tol=tol, abs_tol=1e-6), (k, a[k], b[k])
+    assert r["grad_cos"] > 0.9999 and r["grad_rel_err"] < 2e-2, r
+    assert r["bn_running_mean_err"] < 1e-6, r
