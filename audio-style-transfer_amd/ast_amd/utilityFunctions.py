@@ -77,16 +77,21 @@ def get_overlap_windows(spectrogram, window_size=WINDOW_SIZE, overlap_frames=OVE
 
 
 def sections2spectrogram(sections, original_size, overlap=OVERLAP_FRAMES):
-    """utilityFunctions.py:265-283: overlap-average."""
-    n_sections, _, wind, n_freq = sections.shape
+    """utilityFunctions.py:265-283: count-normalised overlap-average, (S,2,wind,F) -> (2,original_size,F), as one
+    HIP kernel (ast_sections_overlap_avg)."""
+    return sections2spectrogram_batch(sections.unsqueeze(0), original_size, overlap)[0]
+
+
+def sections2spectrogram_batch(sections, original_size, overlap=OVERLAP_FRAMES, n_bins=None):
+    """Batched form: (B,S,2,wind,F) -> (B,2,original_size,n_bins or F)."""
+    B, S, _, wind, F = sections.shape
     hop = wind - overlap
-    n_time = hop * (n_sections - 1) + wind
-    full = sections.new_zeros((2, n_time, n_freq))
-    count = sections.new_zeros((1, n_time, 1))
-    for i in range(n_sections):
-        full[:, i * hop:i * hop + wind] += sections[i]
-        count[:, i * hop:i * hop + wind] += 1.0
-    return (full / count.clamp(min=1.0))[:, :original_size]
+    n_bins = F if n_bins is None else n_bins
+    out_T = min(int(original_size), hop * (S - 1) + wind)
+    sec = sections.float().contiguous()
+    out = torch.empty((B, 2, out_T, n_bins), dtype=torch.float32, device=sec.device)
+    check(lib().ast_sections_overlap_avg(ptr(sec), ptr(out), B, S, wind, hop, F, n_bins, out_T, stream()), "ast_sections_overlap_avg")
+    return out
 
 
 def concat_stft_cqt(stft, cqt):
@@ -102,11 +107,16 @@ def inverse_STFT(stft_tensor, n_fft=1024, hop_length=256):
     """utilityFunctions.py:62-82: (2, T, 513) -> waveform (256*(T-1),) via the HIP inverse-FFT + overlap-add kernels."""
     if n_fft != 1024 or hop_length != 256:
         raise NotImplementedError("the HIP front-end is built for n_fft=1024, hop=256 (the reference's only configuration)")
-    spec = stft_tensor.float().contiguous()
-    T = spec.shape[1]
-    frames = torch.empty((T, 1024), dtype=torch.float32, device=spec.device)
-    wave = torch.empty(256 * (T - 1), dtype=torch.float32, device=spec.device)
-    check(lib().ast_istft(ptr(spec), 1, T, ptr(frames), ptr(wave), stream()), "ast_istft")
+    return inverse_STFT_batch(stft_tensor.unsqueeze(0))[0]
+
+
+def inverse_STFT_batch(spec):
+    """(B, 2, T, 513) -> (B, 256*(T-1)) waveforms in one launch pair."""
+    spec = spec.float().contiguous()
+    B, _, T, _ = spec.shape
+    frames = torch.empty((B, T, 1024), dtype=torch.float32, device=spec.device)
+    wave = torch.empty((B, 256 * (T - 1)), dtype=torch.float32, device=spec.device)
+    check(lib().ast_istft(ptr(spec), B, T, ptr(frames), ptr(wave), stream()), "ast_istft")
     return wave
 
 

@@ -132,6 +132,50 @@ __global__ void istft_ola_kernel(const float* __restrict__ frames, int T, int no
 }
 }  // namespace
 
+namespace {
+// sections2spectrogram (utilityFunctions.py:265-283): count-normalised overlap-average of S windows of `wind` frames at
+// step `hop` back to one (2, n_time, F) spectrogram per clip, truncated to `out_T` frames.  One thread per 4 bins.
+__global__ __launch_bounds__(256) void overlap_avg_kernel(const float* __restrict__ sec, float* __restrict__ out, int S, int wind,
+                                                          int hop, int F_in, int F_out, int out_T, size_t total4) {
+  const int f4n = (F_out + 3) >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+    const int f = (int)(i % f4n) * 4;
+    size_t r = i / f4n;
+    const int t = (int)(r % out_T); r /= out_T;
+    const int c = (int)(r % 2);
+    const size_t b = r / 2;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int cnt = 0;
+    const int i_hi = min(S - 1, t / hop), i_lo = max(0, (t - wind + hop) / hop);
+    for (int k = i_lo; k <= i_hi; ++k) {
+      const int tt = t - k * hop;
+      if (tt < 0 || tt >= wind) continue;
+      const float* p = sec + ((((b * S + k) * 2 + c) * wind + tt) * (size_t)F_in) + f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (f + q < F_out) acc[q] += p[q];
+      ++cnt;
+    }
+    const float inv = 1.f / (float)max(cnt, 1);
+    float* o = out + ((b * 2 + c) * (size_t)out_T + t) * F_out + f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (f + q < F_out) o[q] = acc[q] * inv;
+  }
+}
+}  // namespace
+
+extern "C" int ast_sections_overlap_avg(const float* sections, float* out, int Bc, int S, int wind, int hop, int F_in, int F_out,
+                                        int out_T, void* stream) {
+  if (!sections || !out || Bc < 1 || S < 1 || wind < 1 || hop < 1 || hop > wind || F_out < 1 || F_out > F_in || out_T < 1 ||
+      out_T > hop * (S - 1) + wind)
+    AST_FAIL("ast_sections_overlap_avg: bad args");
+  const size_t total4 = (size_t)Bc * 2 * out_T * ((F_out + 3) / 4);
+  const unsigned grid = (unsigned)std::min<size_t>((total4 + 255) / 256, 4096);
+  hipLaunchKernelGGL(overlap_avg_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, sections, out, S, wind, hop, F_in, F_out, out_T,
+                     total4);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int ast_istft(const float* spec, int Bc, int T, float* frames_ws, float* wave, void* stream) {
   if (!spec || !frames_ws || !wave || Bc <= 0 || T <= 1) AST_FAIL("ast_istft: bad args");
   hipStream_t s = (hipStream_t)stream;

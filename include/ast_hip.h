@@ -247,6 +247,10 @@ int ast_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
 /* inverse_STFT (utilityFunctions.py:62-82; torch.istft defaults): spec (Bc,2,T,513) f32 -> wave (Bc, 256*(T-1));
  * frames_ws: Bc*T*1024 floats of scratch. */
 int ast_istft(const float* spec, int Bc, int T, float* frames_ws, float* wave, void* stream);
+/* sections2spectrogram (utilityFunctions.py:265-283): sections (Bc,S,2,wind,F_in) -> out (Bc,2,out_T,F_out), the
+ * count-normalised overlap-average at step `hop`, bins [0,F_out) only, truncated to out_T <= hop*(S-1)+wind frames. */
+int ast_sections_overlap_avg(const float* sections, float* out, int Bc, int S, int wind, int hop, int F_in, int F_out,
+                             int out_T, void* stream);
 int ast_stft_sections(const float* wave, int Bc, int nsamp, const float* mean, const float* std_,
                       float* x, int S, int win, int step, int F_total, void* stream);
 
