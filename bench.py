@@ -97,7 +97,15 @@ def kernel_roofline(trainer, x, labels, dtype_name):
         roof = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}
     else:
         roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
-    roof.update({"traffic": None, "kernel": name, "launches_per_step": cnt // nsteps, "avg_launch_us": t / cnt * 1e6,
+    traffic, traffic_src = None, None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "d_pmc_traffic.json")
+    if os.path.exists(pmc):
+        # HBM bytes per launch from rocprofv3 PMC passes over this same workload (tools/pmc_traffic.sh + .py: separate
+        # FETCH_SIZE / WRITE_SIZE runs, KiB units, gfx950 x2 fetch correction); counters cannot be read in-process
+        rec = json.load(open(pmc)).get(name)
+        if rec:
+            traffic, traffic_src = rec["traffic_bytes"], "profiles/r01/d_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB->bytes, mean per launch)"
+    roof.update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "kernel": name, "launches_per_step": cnt // nsteps, "avg_launch_us": t / cnt * 1e6,
                  "algorithmic_flops_per_launch": fl / cnt, "algorithmic_bytes_per_launch": by / cnt,
                  "tflops": tf, "frac_of_mfma_peak": tf / peak, "gbs": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS,
                  "gemm_time_per_step_ms": total_t / nsteps * 1e3,
