@@ -46,6 +46,8 @@ _SIGS = {
     "ast_wgrad": ([vp, vp, vp, C.POINTER(Gather), i32, vp], i32),
     "ast_skinny_gemm": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "ast_skinny_gemm_ex": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, f32, C.c_uint64, vp, vp], i32),
+    "ast_bigk_gemm": ([vp, vp, vp, vp, i32, i32, i32, i32, vp], i32),
+    "ast_bign_dgrad": ([vp, vp, vp, i32, i32, i32, i32, vp], i32),
     "ast_linear_wgrad": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "ast_linear_wgrad_batched": ([vp, i32, i32, vp], i32),
     "ast_nchw_to_nhwc": ([vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, i32, vp], i32),

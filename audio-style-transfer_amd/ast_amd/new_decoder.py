@@ -184,9 +184,13 @@ class Decoder(nn.Module):
 def compute_comprehensive_loss(output, target, lambda_temporal=0.3, lambda_phase=0.2, lambda_spectral=0.1):
     """new_decoder.py:348-420 as ONE streaming kernel pass (value + gradient).  Only `total_loss`
     carries gradient; the component entries are detached values."""
+    return _comprehensive_loss(output, target, lambda_temporal, lambda_phase, lambda_spectral, 2.0)
+
+
+def _comprehensive_loss(output, target, lambda_temporal, lambda_phase, lambda_spectral, mse_weight):
     B, S, _, Freq, T = output.shape
     n = B * S * Freq * T
-    c = (2.0 / (2 * n), 0.5 / n, lambda_phase / n,
+    c = (mse_weight / (2 * n), 0.5 / n, lambda_phase / n,
          (lambda_temporal / (2 * B * (S - 1) * Freq * T)) if S > 1 else 0.0,
          (lambda_spectral / (2 * B * S * (Freq - 1) * T)) if Freq > 1 else 0.0)
     total, sums = ops.ReconTotalFn.apply(output.contiguous(), target, c)

@@ -313,6 +313,48 @@ class LinearFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class BigLinearFn(torch.autograd.Function):
+    """nn.Linear with one HUGE dimension on <= 64 token rows, straight on the f32 parameter (no packed copies: the
+    weight is 301 MB) -- SimpleDecoder_TransformerOnly.py:16-17.  in_features huge: ast_bigk_gemm (the input is data,
+    no input gradient exists on the reference's path); out_features huge: ast_skinny_gemm forward, ast_bign_dgrad
+    backward.  Weight/bias gradients: ast_linear_wgrad into the parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        rows, K = x.shape
+        N = weight.shape[0]
+        assert weight.shape[1] == K and x.dtype == torch.float32 and weight.is_contiguous()
+        if rows > SKINNY_MAX_ROWS:
+            raise RuntimeError(f"BigLinearFn: {rows} token rows > {SKINNY_MAX_ROWS}")
+        y = torch.empty((rows, N), dtype=torch.float32, device=x.device)
+        ctx.big_in = K > N
+        if ctx.big_in:
+            check(lib().ast_bigk_gemm(ptr(x), ptr(weight), ptr(bias), ptr(y), rows, N, K, N, stream()), "ast_bigk_gemm")
+        else:
+            check(lib().ast_skinny_gemm(ptr(x), ptr(weight), ptr(bias), ptr(y), rows, N, K, K, N, 0, stream()), "ast_skinny_gemm")
+        ctx.save_for_backward(x)
+        ctx.weight, ctx.bias = weight, bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w, b = ctx.weight, ctx.bias
+        dy = dy.contiguous()
+        rows, K = x.shape
+        N = w.shape[0]
+        check(lib().ast_linear_wgrad(ptr(dy), ptr(x), ptr(acc_grad(w)), ptr(acc_grad(b)) if b is not None else None, rows, N, K, N, K,
+                                     stream()), "ast_linear_wgrad")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.big_in:
+                raise NotImplementedError("BigLinearFn: input gradient of the huge-input linear (its input is data on the reference's path)")
+            dx = torch.empty_like(x)
+            check(lib().ast_bign_dgrad(ptr(dy), ptr(w), ptr(dx), rows, N, K, N, stream()), "ast_bign_dgrad")
+        return dx, None, None
+
+
 class FFNFn(torch.autograd.Function):
     """linear2(dropout(relu(linear1(x)))) on <= 64 token rows in two launches forward and two backward
     (transformer.py _ff_block as style_encoder.py:181-187 / new_decoder.py:111-118 use it): the dropout mask is

@@ -54,6 +54,7 @@ class TrainConfig:
     # Needs a collective per BN layer, so the step runs eagerly; the default keeps per-rank statistics and losses
     # (valid DDP, not loss-matched) and runs as three hipGraphs.
     loss_matched: bool = False
+    decoder: str = "new"          # "new" = new_decoder.Decoder (north star); "simple" = SimpleDecoder_TransformerOnly.Decoder (8(f)1)
     keep_grads: bool = False      # eager mode: keep a copy of the (all-reduced) generator gradient for tests
 
 
@@ -109,7 +110,13 @@ class Trainer:
         self.rank, self.world = rank, world
         torch.manual_seed(seed)                      # identical replicas on every rank
         self.style, self.content = StyleEncoder(), ContentEncoder()
-        self.decoder, self.disc = Decoder(), Discriminator()
+        self._simple = self.cfg.decoder == "simple"
+        if self._simple:
+            from . import SimpleDecoder_TransformerOnly as SD
+            self.decoder, self._rec_loss = SD.Decoder(), SD.compute_comprehensive_loss
+        else:
+            self.decoder, self._rec_loss = Decoder(), compute_comprehensive_loss
+        self.disc = Discriminator()
         if init == "reference":
             # a freshly built reference decoder has all BN/LN gammas = 0 and outputs 0:
             # give the gammas their conventional value 1 so the step does real work
@@ -167,11 +174,13 @@ class Trainer:
             with torch.cuda.stream(s2):
                 content_emb = self.content(x)
             with torch.cuda.stream(s3):
-                y_emb = self.decoder.encode_target(y)
+                if not self._simple:
+                    y_emb = self.decoder.encode_target(y)
             for st in self._streams:
                 main.wait_stream(st)
             for t in (style_emb, class_emb, content_emb, y_emb):
-                t.record_stream(main)
+                if t is not None:
+                    t.record_stream(main)
         elif self._matched:
             style_emb, _ = self.style(x, None)
             content_emb = self.content(x)
@@ -195,8 +204,11 @@ class Trainer:
     def _g_phase(self, x, y, labels_host, style_emb, class_emb, content_emb):
         c = self.cfg
         idx = ops.const_tensor(tuple(int(v) for v in labels_host.tolist()), torch.long, self.device)
-        out = self.decoder(content_emb, class_emb.index_select(0, idx), y=y, y_embeddings=self._y_emb)
-        rec = compute_comprehensive_loss(out, y)
+        if self._simple:
+            out = self.decoder(content_emb, class_emb.index_select(0, idx), y=y)
+        else:
+            out = self.decoder(content_emb, class_emb.index_select(0, idx), y=y, y_embeddings=self._y_emb)
+        rec = self._rec_loss(out, y)
         total = c.w_rec * rec["total_loss"]
         parts = {"rec": rec["total_loss"].detach()}
         total = total + c.w_margin * margin_loss(class_emb)

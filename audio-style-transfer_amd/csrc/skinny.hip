@@ -131,6 +131,105 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     if (g == 0 && nv) db[n0 + i] += bsum;
   }
 }
+// ---- the two 294 462 x 256 linears of SimpleDecoder_TransformerOnly.py:16-17 on <= 64 token rows ---------------
+// Both are streams over a 301 MB weight matrix with a few token rows: HBM-bound, f32 MFMA 16x16x4.
+//
+// Y[m][n] += sum_k X[m][k] W[n][k]   (stft_to_embedding: N = 256, K = 2*287*513).  K is even but not a multiple of
+// 4, so rows are only 8-byte aligned: lane (i, g) loads 2 floats at k = kb + 8 s + 2 g and the two MFMAs of a step
+// contract k = 2 g + e over g.  grid = (N/16, M/16, K chunks of 1024); a workgroup's 4 waves split its chunk, reduce
+// through LDS and add the 16x16 partial tile into Y with f32 atomics (Y is pre-zeroed; chunk 0 adds the bias).
+__global__ __launch_bounds__(256) void bigk_gemm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int M, int N, int K,
+                                                         int ldy) {
+  __shared__ f32x4 part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int kb = blockIdx.z * 1024 + wave * 256;
+  const bool nv = n0 + i < N, mv = m0 + i < M;
+  const float* wr = w + (size_t)(nv ? n0 + i : 0) * K;
+  const float* xr = x + (size_t)(mv ? m0 + i : 0) * K;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int sb = 0; sb < 32; sb += 8) {
+    f32x2 wl[8], xl[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int k = kb + (sb + s) * 8 + 2 * g;
+      const bool kv = k < K;                                   // K even: k and k+1 are valid together
+      const f32x2 a = *reinterpret_cast<const f32x2*>(wr + (kv ? k : 0));
+      const f32x2 b = *reinterpret_cast<const f32x2*>(xr + (kv ? k : 0));
+      const f32x2 z = {0.f, 0.f};
+      wl[s] = (kv && nv) ? a : z;
+      xl[s] = (kv && mv) ? b : z;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s][e], xl[s][e], acc, 0, 0, 0);
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave != 0) return;
+  f32x4 r = part[0][lane];
+#pragma unroll
+  for (int q = 1; q < 4; ++q) { const f32x4 t = part[q][lane]; r[0] += t[0]; r[1] += t[1]; r[2] += t[2]; r[3] += t[3]; }
+  const int m = m0 + i, nb = n0 + 4 * g;                      // D[row = 4 g + r (n)][col = i (m)]
+  if (m >= M) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = nb + q;
+    if (n < N) unsafeAtomicAdd(y + (size_t)m * ldy + n, r[q] + ((bias && blockIdx.z == 0) ? bias[n] : 0.f));
+  }
+}
+
+// dX[m][k] += sum_n dY[m][n] W[n][k]   (data gradient of embedding_to_stft: N = 2*287*513 contracted, K = 256 kept).
+// A workgroup owns a chunk of 512 n for ALL k: wave w keeps the k tiles 4w..4w+3 (D[k][m] = sum_n W[n][k] dY[m][n];
+// lane (i, g): A = W[nb + 4 s + g][k0 + i], 16 lanes = 64 contiguous bytes of a weight row; B = dY[m0 + i][nb + 4 s + g]).
+__global__ __launch_bounds__(256) void bign_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                          float* __restrict__ dx, int M, int N, int K, int lddy) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int nb0 = blockIdx.x * 512, m0 = blockIdx.y * 16;
+  const int kt0 = wave * 4;                                    // first of this wave's four 16-wide k tiles (K <= 256)
+  const bool mv = m0 + i < M;
+  const float* dr = dy + (size_t)(mv ? m0 + i : 0) * lddy;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int sb = 0; sb < 128; sb += 8) {
+    float a[8][4], b[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int n = nb0 + (sb + s) * 4 + g;
+      const bool nvv = n < N;
+      const float bq = dr[nvv ? n : 0];
+      b[s] = (nvv && mv) ? bq : 0.f;
+      const float* wrow = w + (size_t)(nvv ? n : 0) * K;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int k = (kt0 + t) * 16 + i;
+        const float aq = wrow[k < K ? k : 0];
+        a[s][t] = (nvv && k < K) ? aq : 0.f;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][t], b[s], acc[t], 0, 0, 0);
+  }
+  const int m = m0 + i;                                        // D[row = 4 g + r (k)][col = i (m)]
+  if (m >= M) return;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = (kt0 + t) * 16 + 4 * g + r;
+      if (k < K) unsafeAtomicAdd(dx + (size_t)m * K + k, acc[t][r]);
+    }
+}
+
 // Batched form: one launch for every deferred linear weight gradient of a model.
 // table[e] = {dy, x, dW, db, M, N, K, lddy, ldw}; blockIdx.y = entry, blockIdx.x = (k tile, n tile-of-64) of that entry.
 struct LinWg { const float* dy; const float* x; float* dW; float* db; int M, N, K, lddy, ldw, pad0, pad1, pad2; };
@@ -232,6 +331,25 @@ extern "C" int ast_linear_wgrad(const float* dy, const float* x, float* dW, floa
   if (M <= 16) hipLaunchKernelGGL(linear_wgrad_kernel<4>, grid, dim3(256), 0, s, dy, x, dW, db, M, N, K, lddy, ldw);
   else if (M <= 32) hipLaunchKernelGGL(linear_wgrad_kernel<8>, grid, dim3(256), 0, s, dy, x, dW, db, M, N, K, lddy, ldw);
   else hipLaunchKernelGGL(linear_wgrad_kernel<16>, grid, dim3(256), 0, s, dy, x, dW, db, M, N, K, lddy, ldw);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_bigk_gemm(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldy, void* stream) {
+  if (!x || !w || !y || M < 1 || M > 64 || N < 1 || K < 2 || (K & 1)) AST_FAIL("ast_bigk_gemm: bad args M=%d N=%d K=%d (K must be even)", M, N, K);
+  if ((((uintptr_t)x) | ((uintptr_t)w)) & 7) AST_FAIL("ast_bigk_gemm: operands must be 8-byte aligned");
+  dim3 grid((N + 15) / 16, (M + 15) / 16, (K + 1023) / 1024);
+  AST_HIP(hipMemsetAsync(y, 0, sizeof(float) * (size_t)M * ldy, (hipStream_t)stream));
+  hipLaunchKernelGGL(bigk_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, M, N, K, ldy);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_bign_dgrad(const float* dy, const float* w, float* dx, int M, int N, int K, int lddy, void* stream) {
+  if (!dy || !w || !dx || M < 1 || M > 64 || N < 1 || K < 1 || K > 256) AST_FAIL("ast_bign_dgrad: bad args M=%d N=%d K=%d (K <= 256)", M, N, K);
+  dim3 grid((N + 511) / 512, (M + 15) / 16);
+  AST_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)M * K, (hipStream_t)stream));
+  hipLaunchKernelGGL(bign_dgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, w, dx, M, N, K, lddy);
   AST_CHECK_LAUNCH();
   return 0;
 }

@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--infer", action="store_true", help="also time the autoregressive decode (BASELINE configs[3]) and add it to the JSON")
     ap.add_argument("--loss-matched", action="store_true",
                     help="N > 1: sync-BN + gathered batch-coupled losses (global-batch semantics, eager) instead of per-rank statistics")
+    ap.add_argument("--decoder", default="new", choices=["new", "simple"],
+                    help="new_decoder.Decoder (north star) or SimpleDecoder_TransformerOnly.Decoder (SURVEY 8(f)1, 182 M parameters)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -183,7 +185,7 @@ def main():
     import ast_amd
     from ast_amd import train
     ast_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-    tr = train.Trainer(train.TrainConfig(use_graph=not args.no_graph, loss_matched=args.loss_matched), device=dev, rank=rank, world=world)
+    tr = train.Trainer(train.TrainConfig(use_graph=not args.no_graph, loss_matched=args.loss_matched, decoder=args.decoder), device=dev, rank=rank, world=world)
     clip_seconds = {1: 3.0, 2: CLIP_SECONDS, 3: 8.0, 4: 10.0}[args.sections]   # clip length that yields S sections
     if args.no_frontend:
         x, labels = train.synthetic_batch(args.batch, args.sections, dev, seed=1000 + rank)
@@ -219,16 +221,17 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": f"configs[1]: batch={args.batch} {clip_seconds:g} s clips per GPU (S={args.sections}, x=(B,S,2,287,597)), full train2 step: "
                                   + ("" if args.no_frontend else "STFT front-end from resident waveforms (CQT bins synthetic), ")
-                                  + "encoders+decoder+discriminator, all losses, D and G phases, grad clip, Adam",
+                                  + ("encoders+decoder+discriminator" if args.decoder == "new" else "encoders + SimpleDecoder_TransformerOnly (SURVEY 8(f)1, 182 M parameters) + discriminator")
+                                  + ", all losses, D and G phases, grad clip, Adam",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": tr.cfg.use_graph,
                       "dp_semantics": ("global-batch (sync-BN + gathered losses)" if args.loss_matched and world > 1 else "per-rank BN and batch-coupled losses")},
            "losses": losses}
-    if rank == 0 and world == 1 and args.infer:
+    if rank == 0 and world == 1 and args.infer and args.decoder == "new":
         out["autoregressive_decode"] = ar_decode_bench(tr, x, labels, args.sections)
     if rank == 0 and world == 1:
         if not args.no_roofline:
             out["roofline"] = kernel_roofline(tr, x, labels, args.dtype)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.decoder == "new":
             out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))

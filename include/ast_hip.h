@@ -81,6 +81,12 @@ int ast_skinny_gemm(const float* x, const float* w, const float* bias, float* y,
 int ast_skinny_gemm_ex(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldw, int ldy,
                        int relu, const float* mul_mask, float* drop_mask, float p, uint64_t seed, const int64_t* d_offset,
                        void* stream);
+/* The two 2*287*513 x 256 linears of SimpleDecoder_TransformerOnly.py:16-17 on <= 64 token rows (f32, weights streamed once):
+ * ast_bigk_gemm: y[M][N] = x[M][K] w[N][K]^T + bias, K huge and even (stft_to_embedding, :56-60); y is overwritten.
+ * ast_bign_dgrad: dx[M][K] = dy[M][N] w[N][K], N huge, K <= 256 (data gradient of embedding_to_stft, :62-66); dx is overwritten.
+ * (embedding_to_stft forward is ast_skinny_gemm with a huge N; both weight gradients are ast_linear_wgrad.) */
+int ast_bigk_gemm(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int ldy, void* stream);
+int ast_bign_dgrad(const float* dy, const float* w, float* dx, int M, int N, int K, int lddy, void* stream);
 /* dW[n][k] += sum_m dy[m][n] x[m][k]; db[n] += sum_m dy[m][n]  -- straight into the parameter gradients */
 int ast_linear_wgrad(const float* dy, const float* x, float* dW, float* db, int M, int N, int K, int lddy, int ldw,
                      void* stream);

@@ -336,9 +336,38 @@ def decoder_forward(sd, content, class_emb, cfg, y=None, target_length=None, nhe
     return decoder_generate_output(sd, torch.cat(outs, dim=1), cfg)
 
 
-def comprehensive_loss(out, tgt, lambda_temporal=0.3, lambda_phase=0.2, lambda_spectral=0.1):
+def simple_decoder_forward(sd, content, class_emb, cfg, y=None, target_length=None, nhead=4, nlayers=4):
+    """SimpleDecoder_TransformerOnly.py:127-133 (teacher forcing :80-102, autoregressive :104-125): new_decoder's
+    transformer with the CNN halves replaced by two 2*287*513 x 256 linears (:16-17, :56-66)."""
+    memory = decoder_prepare_memory(sd, content, class_emb, cfg)          # same projections + dropout (:72-78)
+    B, d = memory.shape[0], memory.shape[-1]
+
+    def generate(tok):
+        Bq, S, _ = tok.shape
+        return linear(sd, "embedding_to_stft.", layernorm(sd, "output_norm.", tok)).reshape(Bq, S, 2, 287, 513)
+
+    if cfg.training and y is not None:
+        S = y.shape[1]
+        emb = linear(sd, "stft_to_embedding.", y.reshape(B * S, -1)).view(B, S, d)
+        tgt = torch.cat([sd["start_token"].expand(B, 1, -1), emb[:, :-1]], dim=1)
+        tgt = layernorm(sd, "input_norm.", tgt + positional_encoding(S, d))
+        return generate(_decoder_stack(sd, tgt, memory, nhead, nlayers, cfg))
+    if target_length is None:
+        target_length = memory.shape[1] // 2
+    seq = sd["start_token"].expand(B, -1, -1)
+    outs = []
+    for _ in range(target_length):
+        cur = seq + positional_encoding(seq.shape[1], d)
+        nxt = _decoder_stack(sd, cur, memory, nhead, nlayers, cfg)[:, -1:, :]
+        outs.append(nxt)
+        seq = torch.cat([seq, nxt], dim=1)
+    return generate(torch.cat(outs, dim=1))
+
+
+def comprehensive_loss(out, tgt, lambda_temporal=0.3, lambda_phase=0.2, lambda_spectral=0.1, mse_weight=2.0):
     """new_decoder.py:348-420.  dim 1 = sections ("temporal"), dim 3 = the 287
-    axis ("spectral")."""
+    axis ("spectral").  SimpleDecoder_TransformerOnly.py:136-204 is the same function with the MSE term weighted
+    1.0 instead of 2.0 (:194 vs new_decoder.py:406)."""
     mse = ((out - tgt) ** 2).mean()
     mo = torch.sqrt(out[:, :, 0] ** 2 + out[:, :, 1] ** 2 + 1e-8)
     mt = torch.sqrt(tgt[:, :, 0] ** 2 + tgt[:, :, 1] ** 2 + 1e-8)
@@ -351,7 +380,7 @@ def comprehensive_loss(out, tgt, lambda_temporal=0.3, lambda_phase=0.2, lambda_s
     else:
         temporal = torch.zeros(())
     spectral = (((out[:, :, :, 1:] - out[:, :, :, :-1]) - (tgt[:, :, :, 1:] - tgt[:, :, :, :-1])) ** 2).mean()
-    total = 2.0 * mse + 0.5 * mag + lambda_phase * phase + lambda_temporal * temporal + lambda_spectral * spectral
+    total = mse_weight * mse + 0.5 * mag + lambda_phase * phase + lambda_temporal * temporal + lambda_spectral * spectral
     return {"total_loss": total, "mse_loss": mse, "mag_loss": mag, "phase_loss": phase,
             "temporal_loss": temporal, "spectral_loss": spectral}
 

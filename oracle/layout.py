@@ -125,6 +125,27 @@ def decoder_layout():
     return d
 
 
+def simple_decoder_layout():
+    """SimpleDecoder_TransformerOnly.py:9-44 (registration order of the reference)."""
+    d = {"start_token": _f(1, 1, 256)}
+    _linear(d, "stft_to_embedding.", 256, 2 * 287 * 513)
+    _linear(d, "embedding_to_stft.", 2 * 287 * 513, 256)
+    _linear(d, "content_proj.", 256, 256)
+    _linear(d, "class_proj.", 256, 256)
+    d["pos_encoding.pe"] = positional_encoding(500, 256)[None]
+    for i in range(4):
+        b = f"transformer_decoder.layers.{i}."
+        _mha(d, b + "self_attn.", 256)
+        _mha(d, b + "multihead_attn.", 256)
+        _linear(d, b + "linear1.", 1024, 256)
+        _linear(d, b + "linear2.", 256, 1024)
+        for n in ("norm1.", "norm2.", "norm3."):
+            _affine(d, b + n, 256)
+    _affine(d, "input_norm.", 256)
+    _affine(d, "output_norm.", 256)
+    return d
+
+
 def discriminator_layout():
     d = {}
     _linear(d, "net.0.", 128, 256)
@@ -134,7 +155,7 @@ def discriminator_layout():
 
 
 LAYOUTS = {"style": style_encoder_layout, "content": content_encoder_layout,
-           "decoder": decoder_layout, "disc": discriminator_layout}
+           "decoder": decoder_layout, "disc": discriminator_layout, "simple_decoder": simple_decoder_layout}
 
 
 def seeded_model_state(tag: str, requires_grad: bool = True):

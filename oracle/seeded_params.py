@@ -101,6 +101,12 @@ def seeded_input(B: int, S: int, seed: int = 1000, F: int = 597) -> torch.Tensor
     return torch.from_numpy(g.standard_normal((B, S, 2, 287, F)).astype(np.float32))
 
 
+def seeded_normal(shape, seed: int) -> torch.Tensor:
+    """N(0,1) tensor of any shape from its own PCG64 stream (embedding-shaped test inputs)."""
+    g = np.random.default_rng([seed] + list(shape))
+    return torch.from_numpy(g.standard_normal(tuple(shape)).astype(np.float32))
+
+
 def balanced_labels(B: int) -> torch.Tensor:
     """dataloader.py:143-146 -- first half piano (0), second half violin (1)."""
     return torch.cat([torch.zeros(B // 2, dtype=torch.long), torch.ones(B - B // 2, dtype=torch.long)])

@@ -231,3 +231,46 @@ def test_error_surface():
     assert out.shape == (2, 2, 2, 287, 513) and float(out.abs().max()) == 0.0
     with pytest.raises(RuntimeError):
         ast_amd.StyleEncoder()(torch.randn(1, 1, 2, 287, 597))        # CPU tensors: no fallback
+
+
+def test_simple_decoder_f32_vs_golden(golden_dir):
+    """SimpleDecoder_TransformerOnly.Decoder against the real reference's fixtures: teacher-forced
+    output, the 1.0-MSE-weight loss, gradient norms and strided samples of the two 301 MB weight gradients, and the
+    eval-mode autoregressive decode."""
+    from ast_amd import SimpleDecoder_TransformerOnly as SD
+    g = np.load(os.path.join(golden_dir, "simple_b2s2.npz"), allow_pickle=False)
+    ast_amd.set_compute_dtype(torch.float32)
+    m = SD.Decoder()
+    m.load_state_dict(sp.seeded_state_dict(m.state_dict(), tag="simple_decoder"))
+    assert sp.layout_digest(m.state_dict()) == bytes(g["layout_digest"]).decode()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    m = m.to(DEV).train()
+    B, S = 2, 2
+    content, cls = sp.seeded_normal((B, S, 256), 4101).to(DEV), sp.seeded_normal((B, 256), 4102).to(DEV)
+    y = sp.seeded_input(B, S, seed=4103, F=513).to(DEV)
+    assert rel_err(m.encode_input(y), torch.from_numpy(g["y_emb"])) < 1e-3
+    out = m(content, cls, y=y)
+    rec = SD.compute_comprehensive_loss(out, y)
+    rec["total_loss"].backward()
+    torch.cuda.synchronize()
+    assert rel_err(out[:, :, :, ::11, ::13], torch.from_numpy(g["out_sub"])) < 1e-3
+    assert math.isclose(float(out.abs().sum()), float(g["out_abs"]), rel_tol=1e-3)
+    for k in ("total_loss", "mse_loss", "mag_loss", "phase_loss", "temporal_loss", "spectral_loss"):
+        assert math.isclose(float(rec[k]), float(g["rec_" + k]), rel_tol=1e-3, abs_tol=1e-6), k
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref = float(g["gn/" + k])
+        if ref > 1e-6:
+            worst = max(worst, abs(float(p.grad.norm()) - ref) / ref)
+    assert worst < 3e-2, worst
+    assert rel_err(m.stft_to_embedding.weight.grad[::17, ::9973], torch.from_numpy(g["gw_in_sample"])) < 5e-3
+    assert rel_err(m.embedding_to_stft.weight.grad[::9973, ::17], torch.from_numpy(g["gw_out_sample"])) < 5e-3
+    assert rel_err(m.embedding_to_stft.bias.grad[::9973], torch.from_numpy(g["gb_out_sample"])) < 5e-3
+    m.eval()
+    with torch.no_grad():
+        inf = m(content, cls)
+    assert rel_err(inf[:, :, :, ::11, ::13], torch.from_numpy(g["infer_sub"])) < 1e-3

@@ -279,6 +279,40 @@ def test_layernorm():
     assert rel_err(xh.grad, xr.grad) < 1e-4 and rel_err(ln.weight.grad, wr.grad) < 1e-4 and rel_err(ln.bias.grad, br.grad) < 1e-4
 
 
+@pytest.mark.parametrize("rows", [4, 20])
+def test_big_linears_of_simple_decoder(rows):
+    """ast_bigk_gemm / ast_skinny_gemm(N huge) / ast_bign_dgrad / ast_linear_wgrad on the 2*287*513 x 256 linears of
+    SimpleDecoder_TransformerOnly.py:16-17 (dimension cut to 70 002 here: even, not a multiple of 4, like 294 462)."""
+    torch.manual_seed(23)
+    BIG = 70002
+    lin_in, lin_out = nn.Linear(BIG, 256).to(DEV), nn.Linear(256, BIG).to(DEV)
+    with torch.no_grad():
+        lin_in.bias.normal_(0, 0.1); lin_out.bias.normal_(0, 0.1)
+    x = torch.randn(rows, BIG) * 0.1
+    h = torch.randn(rows, 256)
+    # huge input dimension
+    wr, br = lin_in.weight.detach().cpu().clone().requires_grad_(True), lin_in.bias.detach().cpu().clone().requires_grad_(True)
+    yr = F.linear(x, wr, br)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    y = ops.BigLinearFn.apply(x.to(DEV), lin_in.weight, lin_in.bias)
+    assert rel_err(y, yr) < 2e-4
+    y.backward(gy.to(DEV))
+    assert rel_err(lin_in.weight.grad, wr.grad) < 2e-4 and rel_err(lin_in.bias.grad, br.grad) < 2e-4
+    # huge output dimension, with input gradient
+    wr, br = lin_out.weight.detach().cpu().clone().requires_grad_(True), lin_out.bias.detach().cpu().clone().requires_grad_(True)
+    hr = h.clone().requires_grad_(True)
+    yr = F.linear(hr, wr, br)
+    gy = torch.randn_like(yr) * 0.1
+    yr.backward(gy)
+    hh = h.to(DEV).requires_grad_(True)
+    y = ops.BigLinearFn.apply(hh, lin_out.weight, lin_out.bias)
+    assert rel_err(y, yr) < 2e-4
+    y.backward(gy.to(DEV))
+    assert rel_err(hh.grad, hr.grad) < 2e-4
+    assert rel_err(lin_out.weight.grad, wr.grad) < 2e-4 and rel_err(lin_out.bias.grad, br.grad) < 2e-4
+
+
 @pytest.mark.parametrize("rows", [6, 24])
 def test_ffn_fused(rows):
     """FFNFn = linear2(dropout(relu(linear1(x)))): exact against torch at p = 0; at p > 0 the mask is replayed

@@ -125,3 +125,22 @@ def test_inference_session_graph_matches_eager_and_reference_tail():
         wave = FO.istft(spec)
         err = float((torch.from_numpy(wave) - w0[b].cpu()).abs().max()) / (float(abs(wave).max()) + 1e-12)
         assert err < 1e-4, err
+
+
+def test_trainer_with_simple_decoder_graph_matches_eager():
+    """the same train step around SimpleDecoder_TransformerOnly.Decoder (182 M parameters, 0.73 GB of
+    gradients), replayed as a hipGraph, equals the eager step."""
+    ast_amd.set_compute_dtype(torch.float32)
+    x, labels = train.synthetic_batch(2, 2, "cuda:0", seed=4)
+    res = []
+    for use_graph in (False, True):
+        tr = train.Trainer(train.TrainConfig(use_graph=use_graph, dropout=False, decoder="simple"), seed=5)
+        assert tr.G.n > 180_000_000
+        h = [{k: float(v) for k, v in tr.step(x, labels).items()} for _ in range(2)]
+        res.append(h)
+        del tr
+        torch.cuda.empty_cache()
+    for a, b in zip(*res):
+        for k in a:
+            assert math.isfinite(a[k]) and math.isclose(a[k], b[k], rel_tol=5e-3, abs_tol=1e-5), (k, a[k], b[k])
+    assert res[0][1]["rec"] != res[0][0]["rec"]

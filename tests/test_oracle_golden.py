@@ -183,3 +183,31 @@ def test_frontend(golden_dir):
         win = FO.overlap_windows(spec)
         _close(win, g[f"windows_{s}s"], 0, 0)
         _close(FO.sections_to_spectrogram(win, T), g[f"recon_{s}s"], 1e-6, 1e-6)
+
+
+def test_simple_decoder_oracle_vs_reference(golden_dir):
+    """SimpleDecoder_TransformerOnly.Decoder: oracle restatement against the real reference's
+    teacher-forced step (output, loss, gradients incl. strided samples of the two 301 MB weight gradients) and its
+    eval-mode autoregressive decode."""
+    g = _load(golden_dir, "simple_b2s2.npz")
+    sd = L.seeded_model_state("simple_decoder")
+    assert sp.layout_digest(L.LAYOUTS["simple_decoder"]()) == bytes(g["layout_digest"]).decode()
+    B, S = 2, 2
+    content, cls = sp.seeded_normal((B, S, 256), 4101), sp.seeded_normal((B, 256), 4102)
+    y = sp.seeded_input(B, S, seed=4103, F=513)
+    out = O.simple_decoder_forward(sd, content, cls, O.Cfg(training=True, p_drop=0.0), y=y)
+    rec = O.comprehensive_loss(out, y, mse_weight=1.0)          # SimpleDecoder_TransformerOnly.py:194
+    rec["total_loss"].backward()
+    _close(out[:, :, :, ::11, ::13].detach().numpy(), g["out_sub"])
+    assert math.isclose(float(out.abs().sum()), float(g["out_abs"]), rel_tol=1e-4)
+    for k in ("total_loss", "mse_loss", "mag_loss", "phase_loss", "temporal_loss", "spectral_loss"):
+        assert math.isclose(float(rec[k]), float(g["rec_" + k]), rel_tol=1e-4, abs_tol=1e-6), k
+    for k, v in sd.items():
+        if ("gn/" + k) in g.files:
+            assert math.isclose(float(v.grad.norm()), float(g["gn/" + k]), rel_tol=5e-3, abs_tol=1e-6), k
+    _close(sd["stft_to_embedding.weight"].grad[::17, ::9973].numpy(), g["gw_in_sample"], rtol=5e-3)
+    _close(sd["embedding_to_stft.weight"].grad[::9973, ::17].numpy(), g["gw_out_sample"], rtol=5e-3)
+    _close(sd["embedding_to_stft.bias"].grad[::9973].numpy(), g["gb_out_sample"], rtol=5e-3)
+    with torch.no_grad():
+        inf = O.simple_decoder_forward(sd, content, cls, O.Cfg(training=False, p_drop=0.0))
+    _close(inf[:, :, :, ::11, ::13].numpy(), g["infer_sub"])

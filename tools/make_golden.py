@@ -142,6 +142,41 @@ def run_model_config(B, S, name):
         print("infer ok", float(ar.abs().mean()))
 
 
+def run_simple_decoder(B=2, S=2):
+    """SimpleDecoder_TransformerOnly.Decoder: teacher-forced forward + loss + backward, eval-mode
+    autoregressive decode.  Inputs are seeded (content / class embeddings as N(0,1) rows, y as seeded_input)."""
+    import SimpleDecoder_TransformerOnly as r_simple          # noqa: E402  (reference)
+    m = r_simple.Decoder()
+    sd = m.state_dict()
+    m.load_state_dict(sp.seeded_state_dict(sd, tag="simple_decoder"))
+    no_dropout(m)
+    g = {"layout_digest": np.frombuffer(sp.layout_digest(sd).encode(), dtype=np.uint8)}
+    content = sp.seeded_normal((B, S, 256), 4101)
+    cls = sp.seeded_normal((B, 256), 4102)
+    y = sp.seeded_input(B, S, seed=4103, F=513)
+    m.train()
+    emb = m.encode_input(y)
+    out = m(content, cls, y=y)
+    rec = r_simple.compute_comprehensive_loss(out, y)
+    rec["total_loss"].backward()
+    g["y_emb"] = emb.detach().numpy()
+    g["out_sub"], g["out_sum"], g["out_abs"] = sub(out), float(out.sum()), float(out.abs().sum())
+    for k, v in rec.items():
+        g["rec_" + k] = float(v)
+    for k, p in m.named_parameters():
+        g["gn/" + k] = float(p.grad.norm())
+    # a strided sample of the two big gradients (the full tensors are 301 MB each)
+    g["gw_in_sample"] = m.stft_to_embedding.weight.grad[::17, ::9973].numpy().copy()
+    g["gw_out_sample"] = m.embedding_to_stft.weight.grad[::9973, ::17].numpy().copy()
+    g["gb_out_sample"] = m.embedding_to_stft.bias.grad[::9973].numpy().copy()
+    m.eval()
+    with torch.no_grad():
+        inf = m(content, cls)
+    g["infer_sub"], g["infer_sum"] = sub(inf), float(inf.sum())
+    np.savez_compressed(os.path.join(OUT, f"simple_b{B}s{S}.npz"), **g)
+    print("simple decoder: loss", float(rec["total_loss"]), "out_abs", g["out_abs"])
+
+
 def run_losses():
     g = {}
     disc, _ = build("disc")
@@ -218,4 +253,6 @@ if __name__ == "__main__":
         run_model_config(2, 2, "b2s2")
     if "b4s1" in which:
         run_model_config(4, 1, "b4s1")
+    if "simple" in which:
+        run_simple_decoder(2, 2)
     assert not os.path.exists(os.path.join(REF, "__pycache__")), "bytecode leaked into the reference tree"
