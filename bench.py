@@ -224,6 +224,7 @@ def main():
                                   + ("encoders+decoder+discriminator" if args.decoder == "new" else "encoders + SimpleDecoder_TransformerOnly (SURVEY 8(f)1, 182 M parameters) + discriminator")
                                   + ", all losses, D and G phases, grad clip, Adam",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": tr.cfg.use_graph,
+                      "grad_allreduce": ("bf16" if tr._wire_dtype == torch.bfloat16 else "f32") if world > 1 else None,
                       "dp_semantics": ("global-batch (sync-BN + gathered losses)" if args.loss_matched and world > 1 else "per-rank BN and batch-coupled losses")},
            "losses": losses}
     if rank == 0 and world == 1 and args.infer and args.decoder == "new":
