@@ -163,6 +163,28 @@ __global__ __launch_bounds__(256) void overlap_avg_kernel(const float* __restric
 }
 }  // namespace
 
+namespace {
+// dataloader.py:9-13 normalize: (x - mean[c][f]) / (std[c][f] + eps) over a (C, T, F) spectrogram
+__global__ __launch_bounds__(256) void zscore_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                     const float* __restrict__ std_, float* __restrict__ out, int T, int F, float eps,
+                                                     size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int f = (int)(i % F);
+    const int c = (int)(i / ((size_t)T * F));
+    out[i] = (x[i] - mean[(size_t)c * F + f]) / (std_[(size_t)c * F + f] + eps);
+  }
+}
+}  // namespace
+
+extern "C" int ast_zscore(const float* x, const float* mean, const float* std_, float* out, int C, int T, int F, float eps, void* stream) {
+  if (!x || !mean || !std_ || !out || C < 1 || T < 1 || F < 1) AST_FAIL("ast_zscore: bad args");
+  const size_t total = (size_t)C * T * F;
+  hipLaunchKernelGGL(zscore_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, x, mean,
+                     std_, out, T, F, eps, total);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int ast_sections_overlap_avg(const float* sections, float* out, int Bc, int S, int wind, int hop, int F_in, int F_out,
                                         int out_T, void* stream) {
   if (!sections || !out || Bc < 1 || S < 1 || wind < 1 || hop < 1 || hop > wind || F_out < 1 || F_out > F_in || out_T < 1 ||

@@ -614,3 +614,44 @@ def test_optimizer_kernels():
         check(lib().ast_counter_incr(ptr(step), stream()))
         check(lib().ast_adam(ptr(p), ptr(g), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0.0, ptr(step), ptr(nrm), 1.0, stream()))
     assert rel_err(p, ref_p) < 1e-5
+
+
+def test_dataloader_itemwise_api_matches_fused_frontend_and_oracle(tmp_path):
+    """dataloader.py drop-in: normalize / concat_stft_cqt / custom_collate_fn / get_dataloader item by item equal the
+    fused stft_sections kernel on the batch and the oracle's restatement (dataloader.py:9-18,94-147)."""
+    from ast_amd import dataloader as DL
+    from ast_amd import utilityFunctions as U
+    rng = np.random.default_rng(5)
+    mean = torch.from_numpy(rng.normal(0, 0.5, (2, 513)).astype(np.float32))
+    std = torch.from_numpy(rng.uniform(0.2, 3.0, (2, 513)).astype(np.float32))
+    cm, cs = torch.zeros(2, 84), torch.ones(2, 84)
+    waves = [torch.from_numpy(FO.synth_waveform(i, "piano" if i % 2 == 0 else "violin", seconds=4.0)) for i in range(4)]
+    items = []
+    for w in waves[:2]:                                   # two dataset items; piano and violin taken from the same pair
+        sec = {}
+        for which, ww in (("piano", w), ("violin", w.flip(0))):
+            stft = DL.normalize(U.get_STFT(ww.to(DEV)), mean, std)
+            cqt = DL.normalize(torch.zeros(2, stft.shape[1], 84, device=DEV), cm, cs)
+            sec[which] = U.get_overlap_windows(DL.concat_stft_cqt(stft, cqt))
+        items.append({**sec, "piano_label": 0, "violin_label": 1})
+    x, labels = DL.custom_collate_fn(items + items)       # batch of 4: only the first half of the items is used
+    assert x.shape == (4, 2, 2, 287, 597) and labels.tolist() == [0, 0, 1, 1]
+    # fused kernel on the same waveforms in collate order
+    order = [waves[0], waves[1], waves[0].flip(0), waves[1].flip(0)]
+    xf = torch.zeros(4, 2, 2, 287, 597, device=DEV)
+    U.stft_sections(torch.stack(order).to(DEV), mean.to(DEV), std.to(DEV), n_sections=2, F_total=597, out=xf)
+    assert rel_err(x[..., :513], xf[..., :513]) < 1e-5 and float(x[..., 513:].abs().max()) == 0.0
+    # oracle: stft -> normalize -> windows
+    ref = FO.overlap_windows(FO.normalize(FO.stft(order[2].numpy()), mean.numpy(), std.numpy()))
+    assert rel_err(x[2, ..., :513], torch.from_numpy(ref.astype(np.float32))) < 1e-4
+    # Dataset/DataLoader plumbing: file listing, odd-batch warning, missing decoders
+    for d in ("p", "v"):
+        (tmp_path / d).mkdir()
+        for i in range(3):
+            (tmp_path / d / f"{i}.wav").write_bytes(b"")
+    dl = DL.get_dataloader(str(tmp_path / "p"), str(tmp_path / "v"), batch_size=3, shuffle=False)
+    assert dl.batch_size == 2 and len(dl.dataset) == 3
+    with pytest.raises(NotImplementedError):
+        dl.dataset[0]
+    with pytest.raises(ValueError):
+        DL.normalize(torch.zeros(2, 3, device=DEV), mean, std)
