@@ -58,7 +58,7 @@ _SIGS = {
     "ast_dropout_fwd": ([vp, vp, vp, i64, f32, C.c_uint64, vp, vp], i32),
     "ast_weight_grad_unpack": ([vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp], i32),
     "ast_chan_stats": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
-    "ast_norm_finalize": ([vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp, vp, vp, vp], i32),
+    "ast_norm_finalize": ([vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp, vp, vp, C.c_long, vp], i32),
     "ast_affine_act": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "ast_norm_bwd_sums": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "ast_norm_bwd_finalize": ([vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),

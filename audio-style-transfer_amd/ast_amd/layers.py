@@ -203,6 +203,39 @@ def bn_act(x, bn: nn.BatchNorm2d, training, relu=True):
     return ops.BatchNormActFn.apply(x, bn.weight, bn.bias, bn, training, relu)
 
 
+def conv_with_stats(x, pw, k, stride, pad, training):
+    """conv(x) plus, in training mode, the [64][C][2] slot table of its output's per-channel (sum, sum of squares)
+    filled by the GEMM epilogue (None when the plan splits K or fusion is switched off: the consumer then runs the
+    separate statistics pass).  The table must be consumed by the very next normalisation on this stream."""
+    stats = None
+    if training and config.fused_bn_stats:
+        N, H, W, Cs = x.shape
+        g, _ = ops.gather_direct(N, H, W, Cs, pw.Cop, k, stride, pad)
+        if ops.stats_fusable(g, ops.dcode(x.dtype)):
+            stats = ops._clean_scratch(ops.STAT_SLOTS * pw.Cop * 2, x.device, tag="bn-stats")
+    return ops.Conv2dFn.apply(x, pw.weight, pw, k, stride, pad, False, stats), stats
+
+
+def convT_bn_act(x, pw, k, stride, pad, out_pad, bn: nn.BatchNorm2d, training, relu=True):
+    """relu?(BatchNorm2d(conv_transpose(x))), statistics from the epilogues of the output-parity-class GEMMs."""
+    stats = None
+    if training and config.fused_bn_stats:
+        N, H, W, Cs = x.shape
+        Ho = (H - 1) * stride - 2 * pad + k + out_pad
+        Wo = (W - 1) * stride - 2 * pad + k + out_pad
+        gs = ops.gathers_transposed(N, H, W, Cs, Ho, Wo, pw.Cop, k, stride, pad)
+        if all(ops.stats_fusable(g, ops.dcode(x.dtype)) for g in gs):
+            stats = ops._clean_scratch(ops.STAT_SLOTS * pw.Cop * 2, x.device, tag="bn-stats")
+    y = ops.ConvT2dFn.apply(x, pw.weight, pw, k, stride, pad, out_pad, False, stats)
+    return ops.BatchNormActFn.apply(y, bn.weight, bn.bias, bn, training, relu, stats)
+
+
+def conv_bn_act(x, pw, k, stride, pad, bn: nn.BatchNorm2d, training, relu=True):
+    """relu?(BatchNorm2d(conv(x))) -- the conv bias has no effect through a batch norm and carries no gradient."""
+    y, stats = conv_with_stats(x, pw, k, stride, pad, training)
+    return ops.BatchNormActFn.apply(y, bn.weight, bn.bias, bn, training, relu, stats)
+
+
 def layer_norm(x, ln: nn.LayerNorm):
     return ops.LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)
 

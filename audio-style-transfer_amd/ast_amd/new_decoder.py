@@ -83,9 +83,9 @@ class Decoder(nn.Module):
     def _encode_nhwc(self, h):
         tr = self.training
         for pw, i, (_, _, s) in zip(self._enc, (0, 3, 6, 9), ENC_CH):
-            h = L.bn_act(L.conv(h, pw, 3, s, 1, False), self.conv_encoder[i + 1], tr, relu=True)
+            h = L.conv_bn_act(h, pw, 3, s, 1, self.conv_encoder[i + 1], tr, relu=True)
         h = ops.AdaptivePoolFn.apply(h, self.F_compressed, self.T_compressed)
-        h = L.bn_act(L.conv(h, self._sp[0], 3, 1, 1, False), self.spatial_projection[1], tr, relu=True)
+        h = L.conv_bn_act(h, self._sp[0], 3, 1, 1, self.spatial_projection[1], tr, relu=True)
         h = L.conv(h, self._sp[1], 1, 1, 0, True)                          # (N,32,16,8): channel 0 is the real one
         flat = ops.CastFn.apply(h[..., 0].reshape(h.shape[0], -1), torch.float32)
         return L.linear(flat, self._f2s)
@@ -102,7 +102,7 @@ class Decoder(nn.Module):
         h = ops.CastFn.apply(h, L.img_dtype()).view(B * S, self.F_compressed, self.T_compressed, 1)
         h = torch.cat([h, h.new_zeros(B * S, self.F_compressed, self.T_compressed, 7)], dim=3)   # pad C 1 -> 8
         for pw, i in zip(self._dec[:4], (0, 3, 6, 9)):
-            h = L.bn_act(L.convT(h, pw, 3, 2, 1, 1, False), self.conv_decoder[i + 1], tr, relu=True)
+            h = L.convT_bn_act(h, pw, 3, 2, 1, 1, self.conv_decoder[i + 1], tr, relu=True)
         h = L.convT(h, self._dec[4], 3, 1, 1, 0, True)                                      # (N,512,256,8)
         out = ops.BilinearToNCHWFn.apply(h, 2, 287, 513)
         return out.view(B, S, 2, 287, 513)

@@ -106,13 +106,26 @@ def _ws_need(g, dt):
     return v
 
 
-def _igemm(src, wgt, bias, dst, g, flags=0):
+STAT_SLOTS = 64
+
+
+def stats_fusable(g, dt):
+    """True when ast_igemm can add the BatchNorm statistics of its output in the epilogue (plans that do not split K)."""
+    return _ws_need(g, dt) == 0
+
+
+def _igemm(src, wgt, bias, dst, g, flags=0, stats=None):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     need = _ws_need(g, dcode(src.dtype))
-    ws = _clean_scratch(need, src.device) if need > 0 else None        # persistent, handed back zeroed by the finish pass
-    check(lib().ast_igemm(ptr(src), ptr(wgt), ptr(bias), ptr(dst), g, dcode(src.dtype), flags | (4 if need > 0 else 0), ptr(ws), need,
+    if stats is not None:                       # [64][Cd][2] slots filled by the epilogue (flags bit 3); never with split-K
+        assert need == 0 and flags == 0
+        ws, need, flags = stats, stats.numel(), 8
+    else:
+        ws = _clean_scratch(need, src.device) if need > 0 else None    # persistent, handed back zeroed by the finish pass
+        flags |= 4 if need > 0 else 0
+    check(lib().ast_igemm(ptr(src), ptr(wgt), ptr(bias), ptr(dst), g, dcode(src.dtype), flags, ptr(ws), need,
                           stream()), "ast_igemm")
     if PROFILE is not None:
         e1.record()
@@ -182,11 +195,11 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d on NHWC (style_encoder.py:50-67, new_decoder.py:29-61)."""
 
     @staticmethod
-    def forward(ctx, x, weight, pw: PackedWeight, k, stride, pad, bias_grad):
+    def forward(ctx, x, weight, pw: PackedWeight, k, stride, pad, bias_grad, stats=None):
         N, H, W, Cs = x.shape
         g, (Ho, Wo) = gather_direct(N, H, W, Cs, pw.Cop, k, stride, pad)
         y = torch.empty((N, Ho, Wo, pw.Cop), dtype=x.dtype, device=x.device)
-        _igemm(x, pw.wf, pw.bias_ptr_tensor(), y, g)
+        _igemm(x, pw.wf, pw.bias_ptr_tensor(), y, g, stats=stats)
         ctx.save_for_backward(x)
         ctx.pw, ctx.geom, ctx.args, ctx.bias_grad = pw, g, (k, stride, pad), bias_grad
         return y
@@ -208,21 +221,21 @@ class Conv2dFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             for g in gathers_transposed(N, dy.shape[1], dy.shape[2], pw.Cop, H, W, Cs, k, stride, pad):
                 _igemm(dy, pw.wb, None, dx, g)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
 class ConvT2dFn(torch.autograd.Function):
     """nn.ConvTranspose2d on NHWC (new_decoder.py:72-96)."""
 
     @staticmethod
-    def forward(ctx, x, weight, pw: PackedWeight, k, stride, pad, out_pad, bias_grad):
+    def forward(ctx, x, weight, pw: PackedWeight, k, stride, pad, out_pad, bias_grad, stats=None):
         N, H, W, Cs = x.shape
         Ho = (H - 1) * stride - 2 * pad + k + out_pad
         Wo = (W - 1) * stride - 2 * pad + k + out_pad
         y = torch.empty((N, Ho, Wo, pw.Cop), dtype=x.dtype, device=x.device)
         b = pw.bias_ptr_tensor()
         for g in gathers_transposed(N, H, W, Cs, Ho, Wo, pw.Cop, k, stride, pad):
-            _igemm(x, pw.wf, b, y, g)
+            _igemm(x, pw.wf, b, y, g, stats=stats)        # the parity classes partition the output: their statistics add up
         ctx.save_for_backward(x)
         ctx.pw, ctx.args, ctx.bias_grad = pw, (k, stride, pad, Ho, Wo), bias_grad
         return y
@@ -246,7 +259,7 @@ class ConvT2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _igemm(dy, pw.wb, None, dx, g)
-        return dx, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
 SKINNY_MAX_ROWS = 64
@@ -431,11 +444,11 @@ def ffn(x2d, pw1, pw2, p, training):
 _scratch = {}
 
 
-def _clean_scratch(n, device):
+def _clean_scratch(n, device, tag=None):
     """Persistent zero-initialised f32 scratch of n floats.  Every kernel pair that uses it (statistics ->
     finalize, split-K GEMM -> finish) hands it back zeroed, so no launch ever needs a memset.  Work on one
     stream is serial, so one buffer per (size, stream) is enough."""
-    key = (n, device, torch.cuda.current_stream(device).cuda_stream)    # streams run concurrently: one scratch each
+    key = (n, device, torch.cuda.current_stream(device).cuda_stream, tag)    # streams run concurrently: one scratch each
     t = _scratch.get(key)
     if t is None:
         t = _scratch[key] = torch.zeros(n, dtype=torch.float32, device=device)
@@ -470,28 +483,31 @@ def _global_sums(sums, n_floats):
     return g
 
 
-def _bn_batch_stats(x, gamma, beta, bn):
-    """(mean, rstd, scale, shift) of a training-mode BatchNorm2d over the local or (sync-BN) global batch."""
+def _bn_batch_stats(x, gamma, beta, bn, stats=None):
+    """(mean, rstd, scale, shift) of a training-mode BatchNorm2d over the local or (sync-BN) global batch.
+    stats: the [64][C][2] slot table the producing conv's epilogue filled (then no statistics pass runs)."""
     N, H, W, C = x.shape
-    sums = _stats(x)
+    rows = STAT_SLOTS if stats is not None else N
+    sums = stats if stats is not None else _stats(x)
+    pixels = N * H * W
     if _SyncBN.world > 1:
-        g = _global_sums(sums, N * C * 2)
-        sums[:N * C * 2].zero_()
+        g = _global_sums(sums, rows * C * 2)
+        sums[:rows * C * 2].zero_()
         out = torch.empty((4, C), dtype=torch.float32, device=x.device)
-        check(lib().ast_norm_finalize(ptr(g), 0, ptr(bn.num_batches_tracked), N, H * W * _SyncBN.world, C, gamma.numel(), 0, ptr(gamma),
+        check(lib().ast_norm_finalize(ptr(g), 0, ptr(bn.num_batches_tracked), rows, 0, C, gamma.numel(), 0, ptr(gamma),
                                       ptr(beta), ptr(bn.running_mean), ptr(bn.running_var), 0, bn.eps, ptr(out[0]), ptr(out[1]),
-                                      ptr(out[2]), ptr(out[3]), stream()), "ast_norm_finalize")
+                                      ptr(out[2]), ptr(out[3]), pixels * _SyncBN.world, stream()), "ast_norm_finalize")
         return out[0], out[1], out[2], out[3]
-    return _finalize(sums, N, H * W, C, gamma.numel(), False, gamma, beta, bn.running_mean, bn.running_var, False, bn.eps, x.device,
-                     nbt=bn.num_batches_tracked)
+    return _finalize(sums, rows, H * W, C, gamma.numel(), False, gamma, beta, bn.running_mean, bn.running_var, False, bn.eps, x.device,
+                     nbt=bn.num_batches_tracked, count=pixels)
 
 
-def _finalize(sums, N, HW, C, Creal, instance, gamma, beta, rm, rv, eval_mode, eps, dev, nbt=None):
+def _finalize(sums, N, HW, C, Creal, instance, gamma, beta, rm, rv, eval_mode, eps, dev, nbt=None, count=0):
     n = N * C if instance else C
     out = torch.empty((4, n), dtype=torch.float32, device=dev)
     mean, rstd, scale, shift = out[0], out[1], out[2], out[3]
     check(lib().ast_norm_finalize(ptr(sums), 1, ptr(nbt), N, HW, C, Creal, int(instance), ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
-                                  int(eval_mode), eps, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), stream()),
+                                  int(eval_mode), eps, ptr(mean), ptr(rstd), ptr(scale), ptr(shift), count, stream()),
           "ast_norm_finalize")
     return mean, rstd, scale, shift
 
@@ -500,11 +516,11 @@ class BatchNormActFn(torch.autograd.Function):
     """relu?(BatchNorm2d(x)) with batch statistics (training) or running stats (eval)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn, training, relu):
+    def forward(ctx, x, gamma, beta, bn, training, relu, stats=None):
         N, H, W, C = x.shape
         Creal = gamma.numel()
         if training:
-            mean, rstd, scale, shift = _bn_batch_stats(x, gamma, beta, bn)
+            mean, rstd, scale, shift = _bn_batch_stats(x, gamma, beta, bn, stats)
         else:
             mean, rstd, scale, shift = _finalize(None, N, H * W, C, Creal, False, gamma, beta, bn.running_mean,
                                                  bn.running_var, True, bn.eps, x.device)
@@ -538,7 +554,7 @@ class BatchNormActFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         check(lib().ast_norm_bwd_apply(ptr(dy), ptr(y), ptr(x), None, ptr(k1), None, ptr(dx), None, N, H * W, C,
                                        int(ctx.relu), dcode(x.dtype), stream()), "ast_norm_bwd_apply")
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 class ResTailFn(torch.autograd.Function):
@@ -546,11 +562,11 @@ class ResTailFn(torch.autograd.Function):
     (style_encoder.py:76-83) as one elementwise pass over both branches."""
 
     @staticmethod
-    def forward(ctx, c2, ds, g1, b1, g2, b2, bn, inn, training):
+    def forward(ctx, c2, ds, g1, b1, g2, b2, bn, inn, training, stats=None):
         N, H, W, C = c2.shape
         Creal = g1.numel()
         if training:
-            m1, r1, s1, f1 = _bn_batch_stats(c2, g1, b1, bn)
+            m1, r1, s1, f1 = _bn_batch_stats(c2, g1, b1, bn, stats)
         else:
             m1, r1, s1, f1 = _finalize(None, N, H * W, C, Creal, False, g1, b1, bn.running_mean, bn.running_var,
                                        True, bn.eps, c2.device)
@@ -587,7 +603,7 @@ class ResTailFn(torch.autograd.Function):
         dc2, dds = torch.empty_like(c2), torch.empty_like(ds)
         check(lib().ast_norm_bwd_apply(ptr(dy), ptr(y), ptr(c2), ptr(ds), ptr(k1), ptr(k2), ptr(dc2), ptr(dds), N, H * W,
                                        C, 1, dcode(c2.dtype), stream()), "ast_norm_bwd_apply")
-        return dc2, dds, None, None, None, None, None, None, None
+        return dc2, dds, None, None, None, None, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -60,10 +60,10 @@ class ResBlock(nn.Module):
     def run(self, x, training):
         p1, p2, pd = self._pw
         idn = L.conv(x, pd, 1, self.stride, 0, False)
-        h = L.bn_act(L.conv(x, p1, 3, self.stride, 1, False), self.bn1, training, relu=True)
-        c2 = L.conv(h, p2, 3, 1, 1, False)
+        h = L.conv_bn_act(x, p1, 3, self.stride, 1, self.bn1, training, relu=True)
+        c2, c2_stats = L.conv_with_stats(h, p2, 3, 1, 1, training)
         inn = self.downsample[1]
-        return ops.ResTailFn.apply(c2, idn, self.bn2.weight, self.bn2.bias, inn.weight, inn.bias, self.bn2, inn, training)
+        return ops.ResTailFn.apply(c2, idn, self.bn2.weight, self.bn2.bias, inn.weight, inn.bias, self.bn2, inn, training, c2_stats)
 
 
 def build_resnet(in_channels, channels_list):

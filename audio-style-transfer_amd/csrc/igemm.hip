@@ -310,6 +310,15 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ s
   // epilogue: lane owns pixel (col) fr of tile j and channels fq*4..fq*4+3 (rows) of tile i
   const bool accumulate = flags & 1, relu = flags & 2;
   const bool split = gridDim.z > 1;
+  // flags bit 3: `ws` is a [64][Cd][2] table of per-channel (sum, sum of squares) slots and the tile adds the
+  // statistics of the values it STORES (BatchNorm2d's batch statistics without a second pass over the output);
+  // slot = tile index mod 64 keeps the f32 atomics off a single address per channel
+  const bool stats = (flags & 8) && !split;
+  float st1[TN][4], st2[TN][4];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st1[i][r] = 0.f; st2[i][r] = 0.f; }
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int m = bm0 + wm * WTM + j * 16 + fr;
@@ -340,7 +349,45 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ s
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += b4[r];
       }
+      if (stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float q = (float)(T)v[r];                      // the value as stored
+          st1[i][r] += q; st2[i][r] += q * q;
+        }
+      }
       store4<T>(drow + co, v, accumulate, relu);
+    }
+  }
+  if (stats) {
+    float* slot = ws + (size_t)(tix & 63) * g.Cd * 2;
+    // reduce over the 16 pixels of the lane group, then spread the (tile, channel, sum|sumsq) values over the 16 lanes
+    // so that ONE atomic instruction per pair of channel tiles carries them all (an atomic costs its issue slot
+    // whatever the number of active lanes: 4-lane atomics per value made this slower than the separate pass)
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = st1[i][r], b = st2[i][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        st1[i][r] = a; st2[i][r] = b;
+      }
+#pragma unroll
+    for (int i0 = 0; i0 < TN; i0 += 2) {
+      float val = 0.f;
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (i0 + ii < TN) {
+            if (fr == ii * 8 + r * 2) val = st1[i0 + ii][r];
+            if (fr == ii * 8 + r * 2 + 1) val = st2[i0 + ii][r];
+          }
+        }
+      const int ii = fr >> 3, r = (fr >> 1) & 3, which = fr & 1;
+      const int co = bn0 + wn * WTN + (i0 + ii) * 16 + fq * 4 + r;
+      if (i0 + ii < TN && co < g.Cd) unsafeAtomicAdd(slot + (size_t)co * 2 + which, val);
     }
   }
 }
@@ -909,6 +956,10 @@ extern "C" int ast_igemm(const void* src, const void* wgt, const float* bias, vo
   hipStream_t s = (hipStream_t)stream;
   IgemmPlan p = plan_igemm(g, M, dtype);
   if (p.nsplit > 1 && (!ws || ws_floats < (long)M * g.Cd)) AST_FAIL("ast_igemm: split-K needs a workspace of %ld floats (ast_igemm_ws_floats)", (long)M * g.Cd);
+  if (flags & 8) {
+    if (p.nsplit > 1) AST_FAIL("ast_igemm: fused channel statistics are not available for a split-K plan (check ast_igemm_plan)");
+    if ((flags & 3) || !ws || ws_floats < 64L * g.Cd * 2) AST_FAIL("ast_igemm: fused channel statistics need plain stores and a zeroed [64][Cd][2] table");
+  }
 #define AST_IG(BM_, BN_, WM_, WN_, K_) return launch_igemm<T, BM_, BN_, WM_, WN_, K_, 2, 1>(src, wgt, bias, dst, g, M, flags, ws, p, s)
 #define AST_IG4(BM_, BN_, WM_, WN_, K_) return launch_igemm<T, BM_, BN_, WM_, WN_, K_, 2, 4>(src, wgt, bias, dst, g, M, flags, ws, p, s)
   AST_DISPATCH_T(dtype, {

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(float* __restrict__ 
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float* running_mean, float* running_var, int eval_mode, float eps,
                                      float* __restrict__ mean, float* __restrict__ rstd,
-                                     float* __restrict__ scale, float* __restrict__ shift) {
+                                     float* __restrict__ scale, float* __restrict__ shift, long count) {
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int total = instance ? N * C : C;
   if (idx >= total) return;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(float* __restrict__ 
       if (zero_sums) { q[0] = 0.f; q[1] = 0.f; }          // leave the shared statistics scratch clean for the next caller
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1);
-    const double cnt = (double)N * HW;
+    const double cnt = count > 0 ? (double)count : (double)N * HW;   // count > 0: the N rows are partial-sum slots, not images
     const double md = (double)s0 / cnt;
     const double vd = fmax((double)s1 / cnt - md * md, 0.0);
     m = (float)md; var = (float)vd;
@@ -361,14 +361,14 @@ extern "C" int ast_chan_stats(const void* x, float* sums, int N, int HW, int C, 
 
 extern "C" int ast_norm_finalize(float* sums, int zero_sums, int64_t* num_batches_tracked, int N, int HW, int C, int Creal, int instance,
                                  const float* gamma, const float* beta, float* running_mean, float* running_var, int eval_mode, float eps,
-                                 float* mean, float* rstd, float* scale, float* shift, void* stream) {
+                                 float* mean, float* rstd, float* scale, float* shift, long count, void* stream) {
   if (!gamma || !beta || !mean || !rstd || !scale || !shift) AST_FAIL("ast_norm_finalize: null pointer");
   if (!eval_mode && !sums) AST_FAIL("ast_norm_finalize: sums required in training mode");
   if (eval_mode && (instance || !running_mean || !running_var)) AST_FAIL("ast_norm_finalize: eval mode needs running stats");
   const int total = instance ? N * C : C;
   hipLaunchKernelGGL(norm_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums, zero_sums,
                      num_batches_tracked, N, HW, C, Creal, instance, gamma, beta, running_mean, running_var, eval_mode, eps, mean, rstd,
-                     scale, shift);
+                     scale, shift, count);
   AST_CHECK_LAUNCH();
   return 0;
 }

@@ -55,7 +55,11 @@ typedef struct ast_gather_t {
  * Replaces: nn.Conv2d fwd/bwd-data (style_encoder.py:50-67, new_decoder.py:29-61),
  * nn.ConvTranspose2d fwd/bwd-data (new_decoder.py:72-96), nn.Linear fwd/bwd-data.
  * flags: bit0 accumulate into dst, bit1 ReLU, bit2 the split-K workspace is already zero (the finish pass
- * always hands it back zeroed, so a persistent workspace never needs a memset). */
+ * always hands it back zeroed, so a persistent workspace never needs a memset), bit3 `ws` is a zeroed
+ * [64][Cd][2] f32 table and every tile adds (sum, sum of squares) of the values it stores into slot
+ * (tile index mod 64): nn.BatchNorm2d's batch statistics without a second pass over the output
+ * (style_encoder.py:54-58, new_decoder.py:30-61).  Only for plans that do not split K (ast_igemm_plan)
+ * and plain stores (bits 0 and 1 clear); reduce with ast_norm_finalize(N = 64, count = pixels). */
 int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst,
               const ast_gather_t* g, int dtype, int flags, float* ws, long ws_floats, void* stream);
 /* f32 workspace (floats) ast_igemm needs for this geometry: >0 when the launch is split over K
@@ -141,12 +145,14 @@ int ast_weight_grad_unpack(const float* dwp, int from_wb, const float* w, const 
  * assume_zeroed (a persistent scratch that ast_norm_finalize(zero_sums=1) handed back clean). */
 int ast_chan_stats(const void* x, float* sums, int N, int HW, int C, int dtype, int assume_zeroed, void* stream);
 /* From sums -> per-channel (batch) or per-(n,c) (instance) scale/shift; updates
- * running stats when running_mean != NULL (momentum 0.1, unbiased var). eval_mode uses running stats. */
+ * running stats when running_mean != NULL (momentum 0.1, unbiased var). eval_mode uses running stats.
+ * count > 0 (batch form): the N rows of `sums` are partial-sum slots (the [64][C][2] table filled by ast_igemm's
+ * flags bit 3) over `count` pixels in total; count == 0: N images of HW pixels. */
 int ast_norm_finalize(float* sums, int zero_sums, int64_t* num_batches_tracked /* +1 when not NULL */,
                       int N, int HW, int C, int Creal, int instance,
                       const float* gamma, const float* beta, float* running_mean, float* running_var,
                       int eval_mode, float eps, float* mean, float* rstd, float* scale, float* shift,
-                      void* stream);
+                      long count, void* stream);
 /* y = act(x*scale[c] + shift[c] + r*scale2[n,c] + shift2[n,c]) ; r may be NULL.
  * flags: bit0 ReLU, bit1 scale/shift are per (n,c) instead of per c. */
 int ast_affine_act(const void* x, const float* scale, const float* shift, const void* r,
