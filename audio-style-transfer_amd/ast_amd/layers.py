@@ -230,6 +230,18 @@ def convT_bn_act(x, pw, k, stride, pad, out_pad, bn: nn.BatchNorm2d, training, r
     return ops.BatchNormActFn.apply(y, bn.weight, bn.bias, bn, training, relu, stats)
 
 
+def res_head(x, p1, pd, stride, training):
+    """(conv1(x), shortcut_conv(x), statistics table of conv1's output or None) -- see ops.ResHeadFn."""
+    stats = None
+    if training and config.fused_bn_stats:
+        N, H, W, Cs = x.shape
+        g, _ = ops.gather_direct(N, H, W, Cs, p1.Cop, 3, stride, 1)
+        if ops.stats_fusable(g, ops.dcode(x.dtype)):
+            stats = ops._clean_scratch(ops.STAT_SLOTS * p1.Cop * 2, x.device, tag="bn-stats")
+    c1, idn = ops.ResHeadFn.apply(x, p1.weight, pd.weight, p1, pd, stride, stats)
+    return c1, idn, stats
+
+
 def conv_bn_act(x, pw, k, stride, pad, bn: nn.BatchNorm2d, training, relu=True):
     """relu?(BatchNorm2d(conv(x))) -- the conv bias has no effect through a batch norm and carries no gradient."""
     y, stats = conv_with_stats(x, pw, k, stride, pad, training)

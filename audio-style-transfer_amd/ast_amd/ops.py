@@ -224,6 +224,48 @@ class Conv2dFn(torch.autograd.Function):
         return dx, None, None, None, None, None, None, None
 
 
+class ResHeadFn(torch.autograd.Function):
+    """The two convolutions that read a ResBlock's input -- conv1 (3x3) and the 1x1 shortcut, both with the block's
+    stride (style_encoder.py:50, 64-70) -- as ONE autograd node: the second data gradient is accumulated into the
+    first one's result by the GEMM epilogue (flags bit 0) instead of an ATen add over the activation map."""
+
+    @staticmethod
+    def forward(ctx, x, w1, wd, pw1: PackedWeight, pwd: PackedWeight, stride, stats):
+        N, H, W, Cs = x.shape
+        g1, (Ho, Wo) = gather_direct(N, H, W, Cs, pw1.Cop, 3, stride, 1)
+        gd, (Hd, Wd) = gather_direct(N, H, W, Cs, pwd.Cop, 1, stride, 0)
+        assert (Ho, Wo) == (Hd, Wd)
+        c1 = torch.empty((N, Ho, Wo, pw1.Cop), dtype=x.dtype, device=x.device)
+        idn = torch.empty((N, Ho, Wo, pwd.Cop), dtype=x.dtype, device=x.device)
+        _igemm(x, pw1.wf, pw1.bias_ptr_tensor(), c1, g1, stats=stats)
+        _igemm(x, pwd.wf, pwd.bias_ptr_tensor(), idn, gd)
+        ctx.save_for_backward(x)
+        ctx.pws, ctx.geoms, ctx.stride = (pw1, pwd), (g1, gd), stride
+        return c1, idn
+
+    @staticmethod
+    def backward(ctx, dc1, didn):
+        (x,) = ctx.saved_tensors
+        (pw1, pwd), (g1, gd), stride = ctx.pws, ctx.geoms, ctx.stride
+        dc1, didn = dc1.contiguous(), didn.contiguous()
+        N, H, W, Cs = x.shape
+        if pw1.dwp is None or pwd.dwp is None:
+            raise RuntimeError("weights were prepared in eval/no-grad mode; run the forward in training mode before backward")
+        _wgrad(dc1, x, pw1.dwp, g1)
+        _wgrad(didn, x, pwd.dwp, gd)
+        pw1.bank.request_flush()                 # both convs feed a normalisation: their biases carry no gradient
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            Ho, Wo = dc1.shape[1], dc1.shape[2]
+            for g in gathers_transposed(N, Ho, Wo, pw1.Cop, H, W, Cs, 3, stride, 1):
+                _igemm(dc1, pw1.wb, None, dx, g)
+            for g in gathers_transposed(N, Ho, Wo, pwd.Cop, H, W, Cs, 1, stride, 0):
+                if g.ntaps > 0:                  # a 1x1 stride-s conv reaches one output-parity class only
+                    _igemm(didn, pwd.wb, None, dx, g, flags=1)
+        return dx, None, None, None, None, None, None
+
+
 class ConvT2dFn(torch.autograd.Function):
     """nn.ConvTranspose2d on NHWC (new_decoder.py:72-96)."""
 

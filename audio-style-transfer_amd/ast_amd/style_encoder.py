@@ -59,8 +59,8 @@ class ResBlock(nn.Module):
 
     def run(self, x, training):
         p1, p2, pd = self._pw
-        idn = L.conv(x, pd, 1, self.stride, 0, False)
-        h = L.conv_bn_act(x, p1, 3, self.stride, 1, self.bn1, training, relu=True)
+        c1, idn, c1_stats = L.res_head(x, p1, pd, self.stride, training)
+        h = ops.BatchNormActFn.apply(c1, self.bn1.weight, self.bn1.bias, self.bn1, training, True, c1_stats)
         c2, c2_stats = L.conv_with_stats(h, p2, 3, 1, 1, training)
         inn = self.downsample[1]
         return ops.ResTailFn.apply(c2, idn, self.bn2.weight, self.bn2.bias, inn.weight, inn.bias, self.bn2, inn, training, c2_stats)
