@@ -84,6 +84,12 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(float* __restrict__ 
   if (idx >= total) return;
   const int c = idx % C;
   float m, var;
+  // per-channel parameters are fetched up front so they overlap the statistics loads instead of trailing them
+  const bool real_c = c < Creal;
+  const float gmm = real_c ? gamma[c] : 0.f, bt = real_c ? beta[c] : 0.f;
+  const bool upd = !instance && !eval_mode && running_mean && real_c;
+  const float rm_old = (upd || (eval_mode && real_c)) ? running_mean[c] : 0.f;
+  const float rv_old = (upd || (eval_mode && real_c)) ? running_var[c] : 1.f;
   if (nbt && idx == 0 && lane == 0) nbt[0] += 1;       // BatchNorm2d.num_batches_tracked
   if (instance) {
     const float cnt = (float)HW;
@@ -91,8 +97,8 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(float* __restrict__ 
     var = fmaxf(sums[(size_t)idx * 2 + 1] / cnt - m * m, 0.f);
     if (zero_sums && lane == 0) { sums[(size_t)idx * 2] = 0.f; sums[(size_t)idx * 2 + 1] = 0.f; }
   } else if (eval_mode) {
-    m = c < Creal ? running_mean[c] : 0.f;
-    var = c < Creal ? running_var[c] : 1.f;
+    m = rm_old;
+    var = rv_old;
   } else {
     float s0 = 0.f, s1 = 0.f;
     for (int n = lane; n < N; n += 64) {
@@ -105,15 +111,14 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(float* __restrict__ 
     const double md = (double)s0 / cnt;
     const double vd = fmax((double)s1 / cnt - md * md, 0.0);
     m = (float)md; var = (float)vd;
-    if (lane == 0 && running_mean && c < Creal) {
-      running_mean[c] = 0.9f * running_mean[c] + 0.1f * m;
-      running_var[c] = 0.9f * running_var[c] + 0.1f * (float)(vd * cnt / fmax(cnt - 1.0, 1.0));
+    if (lane == 0 && upd) {
+      running_mean[c] = 0.9f * rm_old + 0.1f * m;
+      running_var[c] = 0.9f * rv_old + 0.1f * (float)(vd * cnt / fmax(cnt - 1.0, 1.0));
     }
   }
   if (lane != 0) return;
   const float r = rsqrtf(var + eps);
   mean[idx] = m; rstd[idx] = r;
-  const float gmm = c < Creal ? gamma[c] : 0.f, bt = c < Creal ? beta[c] : 0.f;
   scale[idx] = gmm * r;
   shift[idx] = bt - m * gmm * r;
 }

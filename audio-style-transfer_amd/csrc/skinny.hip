@@ -31,21 +31,32 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
   const float* wr = w + (size_t)(nv ? n0 + i : 0) * ldw;
   const float* xr = x + (size_t)(mv ? m0 + i : 0) * ldx;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // the epilogue's bias values (lane: n = n0 + 4 g .. +3) are fetched with the first loads, not after the reduction
+  float bq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int n = n0 + 4 * g + q; bq[q] = bias[n < N ? n : 0]; }
+  }
   f32x4 wl[NS], xl[NS];                               // every load of the wave's K slice is issued before the first MFMA
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int k = kb + s * 16 + 4 * g;
     const bool kv = k < K;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 a = *reinterpret_cast<const f32x4*>(wr + (kv ? k : 0));
-    const f32x4 b = *reinterpret_cast<const f32x4*>(xr + (kv ? k : 0));
-    wl[s] = (kv && nv) ? a : z;
-    xl[s] = (kv && mv) ? b : z;
+    wl[s] = *reinterpret_cast<const f32x4*>(wr + (kv ? k : 0));
+    xl[s] = *reinterpret_cast<const f32x4*>(xr + (kv ? k : 0));
   }
+  // Without this fence the scheduler interleaves load -> s_waitcnt vmcnt(0) -> MFMA per step: 2*NS dependent round trips
+  // (13.5 us per launch at K = 1024 instead of ~4).  The masking selects sit on the far side so they cannot pull
+  // the waits forward.
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
+  for (int s = 0; s < NS; ++s) {
+    const bool kv = kb + s * 16 + 4 * g < K;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 a = (kv && nv) ? wl[s] : z, b = (kv && mv) ? xl[s] : z;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s][e], xl[s][e], acc, 0, 0, 0);
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+  }
   part[wave][lane] = acc;
   __syncthreads();
   if (wave != 0) return;
@@ -64,7 +75,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
     const int n = nb + q;
     if (n < N) {
       const size_t o = (size_t)m * ldy + n;
-      float v = r[q] + (bias ? bias[n] : 0.f);
+      float v = r[q] + bq[q];
       if (relu) v = fmaxf(v, 0.f);
       if (drop_mask) {
         const float km = dropout_keep(base, o, p, keep);
@@ -98,23 +109,38 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
   for (int st = 0; st < MS; ++st) {
     const int m = st * 4 + g;
     const bool mv = m < M;
-    const float a = dy[(size_t)(mv ? m : 0) * lddy + (nv ? n0 + i : 0)];
-    av[st] = (mv && nv) ? a : 0.f;
+    av[st] = dy[(size_t)(mv ? m : 0) * lddy + (nv ? n0 + i : 0)];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int k = k0 + t * 16 + i;
       const bool kv = mv && k < K;
-      const float b = x[(size_t)(kv ? m : 0) * K + (kv ? k : 0)];
-      bv[st][t] = kv ? b : 0.f;
+      bv[st][t] = x[(size_t)(kv ? m : 0) * K + (kv ? k : 0)];
     }
   }
+  __builtin_amdgcn_sched_barrier(0);                       // all loads in flight before the first MFMA (see skinny_gemm_kernel)
 #pragma unroll
   for (int st = 0; st < MS; ++st) {
-    bsum += av[st];
+    const bool mv = st * 4 + g < M;
+    const float a = (mv && nv) ? av[st] : 0.f;
+    bsum += a;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv[st][t], acc[t], 0, 0, 0);
+    for (int t = 0; t < 4; ++t) {
+      const float b = (mv && k0 + t * 16 + i < K) ? bv[st][t] : 0.f;
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+    }
   }
-  // D[row = n0 + 4 g + r][col = k0 + 16 t + i]
+  // D[row = n0 + 4 g + r][col = k0 + 16 t + i]; the 16 old values are fetched together, then added and stored
+  float old[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int k = k0 + t * 16 + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * g + r;
+      old[t][r] = (k < K && n < N) ? dW[(size_t)n * ldw + k] : 0.f;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int k = k0 + t * 16 + i;
@@ -122,7 +148,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = n0 + 4 * g + r;
-      if (n < N) dW[(size_t)n * ldw + k] += acc[t][r];
+      if (n < N) dW[(size_t)n * ldw + k] = old[t][r] + acc[t][r];
     }
   }
   if (db && blockIdx.x == 0) {
@@ -157,16 +183,18 @@ __global__ __launch_bounds__(256) void bigk_gemm_kernel(const float* __restrict_
     for (int s = 0; s < 8; ++s) {
       const int k = kb + (sb + s) * 8 + 2 * g;
       const bool kv = k < K;                                   // K even: k and k+1 are valid together
-      const f32x2 a = *reinterpret_cast<const f32x2*>(wr + (kv ? k : 0));
-      const f32x2 b = *reinterpret_cast<const f32x2*>(xr + (kv ? k : 0));
-      const f32x2 z = {0.f, 0.f};
-      wl[s] = (kv && nv) ? a : z;
-      xl[s] = (kv && mv) ? b : z;
+      wl[s] = *reinterpret_cast<const f32x2*>(wr + (kv ? k : 0));
+      xl[s] = *reinterpret_cast<const f32x2*>(xr + (kv ? k : 0));
     }
+    __builtin_amdgcn_sched_barrier(0);                         // 16 loads in flight together (see skinny_gemm_kernel)
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < 8; ++s) {
+      const bool kv = kb + (sb + s) * 8 + 2 * g < K;
+      const f32x2 z = {0.f, 0.f};
+      const f32x2 a = (kv && nv) ? wl[s] : z, b = (kv && mv) ? xl[s] : z;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[s][e], xl[s][e], acc, 0, 0, 0);
+      for (int e = 0; e < 2; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+    }
   }
   part[wave][lane] = acc;
   __syncthreads();
@@ -204,20 +232,25 @@ __global__ __launch_bounds__(256) void bign_dgrad_kernel(const float* __restrict
     for (int s = 0; s < 8; ++s) {
       const int n = nb0 + (sb + s) * 4 + g;
       const bool nvv = n < N;
-      const float bq = dr[nvv ? n : 0];
-      b[s] = (nvv && mv) ? bq : 0.f;
+      b[s] = dr[nvv ? n : 0];
       const float* wrow = w + (size_t)(nvv ? n : 0) * K;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int k = (kt0 + t) * 16 + i;
-        const float aq = wrow[k < K ? k : 0];
-        a[s][t] = (nvv && k < K) ? aq : 0.f;
+        a[s][t] = wrow[k < K ? k : 0];
       }
     }
+    __builtin_amdgcn_sched_barrier(0);                         // 40 loads in flight together (see skinny_gemm_kernel)
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < 8; ++s) {
+      const bool nvv = nb0 + (sb + s) * 4 + g < N;
+      const float bq = (nvv && mv) ? b[s] : 0.f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][t], b[s], acc[t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) {
+        const float aq = (nvv && (kt0 + t) * 16 + i < K) ? a[s][t] : 0.f;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bq, acc[t], 0, 0, 0);
+      }
+    }
   }
   const int m = m0 + i;                                        // D[row = 4 g + r (k)][col = i (m)]
   if (m >= M) return;
@@ -251,26 +284,42 @@ __global__ __launch_bounds__(256) void linear_wgrad_batched_kernel(const LinWg* 
   for (int st0 = 0; st0 * 4 < e.M; st0 += 4) {          // 4 MFMA k-steps (16 token rows) per batch of loads
     float av[4], bv[4][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 4; ++u) {                          // raw loads first (clamped addresses) ...
       const int m = (st0 + u) * 4 + g;
       const bool mv = m < e.M;
-      const float a = e.dy[(size_t)(mv ? m : 0) * e.lddy + (nv ? n0 + i : 0)];
-      av[u] = (mv && nv) ? a : 0.f;
+      av[u] = e.dy[(size_t)(mv ? m : 0) * e.lddy + (nv ? n0 + i : 0)];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int k = k0 + t * 16 + i;
         const bool kv = mv && k < e.K;
-        const float b = e.x[(size_t)(kv ? m : 0) * e.K + (kv ? k : 0)];
-        bv[u][t] = kv ? b : 0.f;
+        bv[u][t] = e.x[(size_t)(kv ? m : 0) * e.K + (kv ? k : 0)];
       }
     }
+    __builtin_amdgcn_sched_barrier(0);                     // ... so that the 20 loads are in flight together (see skinny_gemm_kernel)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      bsum += av[u];
+      const int m = (st0 + u) * 4 + g;
+      const bool mv = m < e.M;
+      const float a = (mv && nv) ? av[u] : 0.f;
+      bsum += a;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][t], acc[t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) {
+        const float b = (mv && k0 + t * 16 + i < e.K) ? bv[u][t] : 0.f;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+      }
     }
   }
+  float old[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int k = k0 + t * 16 + i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * g + r;
+      old[t][r] = (k < e.K && n < e.N) ? e.dW[(size_t)n * e.ldw + k] : 0.f;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int k = k0 + t * 16 + i;
@@ -278,7 +327,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_batched_kernel(const LinWg* 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = n0 + 4 * g + r;
-      if (n < e.N) e.dW[(size_t)n * e.ldw + k] += acc[t][r];
+      if (n < e.N) e.dW[(size_t)n * e.ldw + k] = old[t][r] + acc[t][r];
     }
   }
   if (e.db && kt == 0) {
