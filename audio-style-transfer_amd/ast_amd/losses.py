@@ -28,17 +28,19 @@ def adversarial_loss(style_emb, class_emb, content_emb, discriminator, labels, c
     """losses.py:69-123."""
     dev = style_emb.device
     if content_emb.dim() == 3:
-        content_emb = content_emb.mean(dim=1)
+        content_emb = ops.mean_over_sections(content_emb)
     lab = _labels32(labels, dev)
     style_pred = discriminator(style_emb)
     content_pred = discriminator(content_emb)
-    d_loss = lambda_style * ops.CrossEntropyFn.apply(style_pred, lab) + lambda_content * ops.CrossEntropyFn.apply(content_pred, lab)
+    def wt(w, t):                         # a weight of exactly 1.0 needs no multiply launch
+        return t if w == 1.0 else w * t
+    d_loss = wt(lambda_style, ops.CrossEntropyFn.apply(style_pred, lab)) + wt(lambda_content, ops.CrossEntropyFn.apply(content_pred, lab))
     if class_emb is not None:
         class_pred = discriminator(class_emb)
         d_loss = d_loss + lambda_class * ops.CrossEntropyFn.apply(class_pred, ops.const_tensor((0, 1), torch.int32, dev))
     if compute_for_discriminator:
         return d_loss, None
-    return d_loss, -lambda_content * ops.SoftmaxEntropyFn.apply(content_pred)
+    return d_loss, -wt(lambda_content, ops.SoftmaxEntropyFn.apply(content_pred))
 
 
 def disentanglement_loss(style_emb: torch.Tensor, content_emb: torch.Tensor, use_hsic: bool = True, weight=20.0) -> torch.Tensor:

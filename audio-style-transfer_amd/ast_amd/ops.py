@@ -742,6 +742,79 @@ def add_drop_ln(x, sub, ln, p, training):
     return (out, None) if ln is None else out
 
 
+class RowMixFn(torch.autograd.Function):
+    """Y = A X for a small constant coefficient matrix A (ast_rowmix); backward is A^T dY."""
+
+    @staticmethod
+    def forward(ctx, x, A, At):
+        x = x.contiguous()
+        R_out, R_in = A.shape
+        assert x.shape[0] == R_in and x.dtype == torch.float32
+        y = torch.empty((R_out, x.shape[1]), dtype=torch.float32, device=x.device)
+        check(lib().ast_rowmix(ptr(A), ptr(x), ptr(y), R_out, R_in, x.shape[1], stream()), "ast_rowmix")
+        ctx.At = At
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        At = ctx.At
+        dy = dy.contiguous()
+        dx = torch.empty((At.shape[0], dy.shape[1]), dtype=torch.float32, device=dy.device)
+        check(lib().ast_rowmix(ptr(At), ptr(dy), ptr(dx), At.shape[0], At.shape[1], dy.shape[1], stream()), "ast_rowmix")
+        return dx, None, None
+
+
+@functools.lru_cache(maxsize=256)
+def _mix_matrices(kind, key, device):
+    """(A, A^T) as device constants.  kind 'proto': rows = present classes ascending, A[c][i] = 1/count_c for label_i == c;
+    'gather': A[b][c] = 1 for class index c of row b; 'mean': key = (B, S), A[b][b*S + s] = 1/S."""
+    if kind == "proto":
+        classes = sorted(set(key))
+        A = torch.zeros(len(classes), len(key))
+        for r, cid in enumerate(classes):
+            idx = [i for i, v in enumerate(key) if v == cid]
+            A[r, idx] = 1.0 / len(idx)
+    elif kind == "gather":
+        classes = sorted(set(key))
+        A = torch.zeros(len(key), len(classes))
+        for b, v in enumerate(key):
+            A[b, classes.index(v)] = 1.0
+    else:
+        B, S = key
+        A = torch.zeros(B, B * S)
+        for b in range(B):
+            A[b, b * S:(b + 1) * S] = 1.0 / S
+    return A.to(device).contiguous(), A.t().contiguous().to(device)
+
+
+def mul_const(x, c):
+    """x * c elementwise for small f32 vectors (no autograd): one ast_mul launch."""
+    y = torch.empty_like(x)
+    check(lib().ast_mul(ptr(x.contiguous()), ptr(c), ptr(y), x.numel(), 0, stream()), "ast_mul")
+    return y
+
+
+def class_means(emb, labels_host):
+    """style_encoder.py:243-253: mean embedding per PRESENT class id, ascending."""
+    A, At = _mix_matrices("proto", tuple(int(v) for v in labels_host.tolist()), emb.device)
+    return RowMixFn.apply(emb, A, At)
+
+
+def class_rows(class_emb, labels_host):
+    """class_emb[row of label_b] for every batch row b (labels as present-class ranks)."""
+    A, At = _mix_matrices("gather", tuple(int(v) for v in labels_host.tolist()), class_emb.device)
+    return RowMixFn.apply(class_emb, A, At)
+
+
+def mean_over_sections(x):
+    """(B,S,d).mean(dim=1)."""
+    B, S, d = x.shape
+    if S == 1:
+        return x.reshape(B, d)
+    A, At = _mix_matrices("mean", (B, S), x.device)
+    return RowMixFn.apply(x.reshape(B * S, d), A, At)
+
+
 # ---------------------------------------------------------------------------
 # pooling / resampling / layout
 # ---------------------------------------------------------------------------

@@ -121,12 +121,7 @@ def _module_bank(mod):
 def class_prototypes(style_emb, labels):
     """style_encoder.py:243-253: mean embedding per PRESENT class id, ascending.  `labels` on the
     host avoids the device sync of labels.unique() (and is required under hipGraph capture)."""
-    lab = labels.tolist()
-    rows = []
-    for cid in sorted(set(lab)):
-        idx = ops.const_tensor(tuple(i for i, v in enumerate(lab) if v == cid), torch.long, style_emb.device)
-        rows.append(style_emb.index_select(0, idx).mean(dim=0))
-    return torch.stack(rows, dim=0)
+    return ops.class_means(style_emb, labels)
 
 
 class StyleEncoder(nn.Module):

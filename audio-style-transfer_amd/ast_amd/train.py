@@ -221,26 +221,29 @@ class Trainer:
 
     def _g_phase(self, x, y, labels_host, style_emb, class_emb, content_emb):
         c = self.cfg
-        idx = ops.const_tensor(tuple(int(v) for v in labels_host.tolist()), torch.long, self.device)
+
+        def wt(w, t):                     # a weight of exactly 1.0 needs no multiply launch (forward and backward)
+            return t if w == 1.0 else w * t
+        cls_rows = ops.class_rows(class_emb, labels_host)
         if self._simple:
-            out = self.decoder(content_emb, class_emb.index_select(0, idx), y=y)
+            out = self.decoder(content_emb, cls_rows, y=y)
         else:
-            out = self.decoder(content_emb, class_emb.index_select(0, idx), y=y, y_embeddings=self._y_emb)
+            out = self.decoder(content_emb, cls_rows, y=y, y_embeddings=self._y_emb)
         rec = self._rec_loss(out, y)
-        total = c.w_rec * rec["total_loss"]
+        total = wt(c.w_rec, rec["total_loss"])
         parts = {"rec": rec["total_loss"].detach()}
-        total = total + c.w_margin * margin_loss(class_emb)
-        style_b, labels_b, content_b = style_emb, labels_host, content_emb.mean(dim=1)
+        total = total + wt(c.w_margin, margin_loss(class_emb))
+        style_b, labels_b, content_b = style_emb, labels_host, ops.mean_over_sections(content_emb)
         if self._matched:                    # batch-coupled terms on the gathered global batch
             style_b, labels_b = self._glob
             content_b = gather_rows(content_b, self.rank, self.world)
         if c.use_nce:
             nce = infoNCE_loss(style_b, labels_b)
-            total = total + c.w_nce * nce
+            total = total + wt(c.w_nce, nce)
             parts["nce"] = nce.detach()
         if c.use_hsic:
             hs = disentanglement_loss(style_b, content_b)
-            total = total + c.w_hsic * hs
+            total = total + wt(c.w_hsic, hs)
             parts["hsic"] = hs.detach()
         if c.use_adv:
             bank_d = _module_bank(self.disc)
@@ -248,7 +251,7 @@ class Trainer:
             bank_d.hold = True
             _, g_adv = adversarial_loss(style_emb, class_emb, content_emb, self.disc, labels_host, False)
             bank_d.hold = False
-            total = total + c.w_adv * g_adv
+            total = total + wt(c.w_adv, g_adv)
             parts["adv_g"] = g_adv.detach()
         total.backward()
         parts["total"] = total.detach()

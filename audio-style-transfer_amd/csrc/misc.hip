@@ -297,6 +297,25 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restric
   }
 }
 
+// Y[o][d] = sum_i A[o][i] X[i][d] for a small dense coefficient matrix A (<= 64 x 64): per-class means of embeddings
+// (style_encoder.py:243-253), the per-row class-prototype gather (new_decoder.py:214-223 callers), means over the
+// section axis (losses.py:88, 142) and their backward passes (A transposed).  One workgroup per output row.
+__global__ __launch_bounds__(256) void rowmix_kernel(const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ Y,
+                                                     int R_in, int D) {
+  const int o = blockIdx.x;
+  __shared__ float a[64];
+  if ((int)threadIdx.x < R_in) a[threadIdx.x] = A[(size_t)o * R_in + threadIdx.x];
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float acc = 0.f;
+    for (int i = 0; i < R_in; ++i) {
+      const float w = a[i];
+      if (w != 0.f) acc += w * X[(size_t)i * D + d];
+    }
+    Y[(size_t)o * D + d] = acc;
+  }
+}
+
 }  // namespace
 
 extern "C" int ast_dropout_fwd(const float* x, float* y, float* mask, int64_t n, float p, uint64_t seed, const int64_t* d_offset,
@@ -441,6 +460,13 @@ extern "C" int ast_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, 
   if (!mask || n < 0 || p < 0.f || p >= 1.f) AST_FAIL("ast_dropout_mask: bad args");
   if (n == 0) return 0;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, mask, (size_t)n, p, seed, d_offset);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_rowmix(const float* A, const float* X, float* Y, int R_out, int R_in, int D, void* stream) {
+  if (!A || !X || !Y || R_out < 1 || R_in < 1 || R_in > 64 || D < 1) AST_FAIL("ast_rowmix: bad args R_out=%d R_in=%d D=%d", R_out, R_in, D);
+  hipLaunchKernelGGL(rowmix_kernel, dim3(R_out), dim3(256), 0, (hipStream_t)stream, A, X, Y, R_in, D);
   AST_CHECK_LAUNCH();
   return 0;
 }
