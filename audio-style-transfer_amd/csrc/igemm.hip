@@ -430,7 +430,8 @@ template <typename T, int BMW, int NCT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ src,
                                                      float* __restrict__ dw, const ast_gather_t g,
                                                      const int P, const int pps, const unsigned dy_bytes,
-                                                     const unsigned src_bytes, const float rcp_hw, const float rcp_w) {
+                                                     const unsigned src_bytes, const float rcp_hw, const float rcp_w,
+                                                     const int gx, const int gy, const int gz) {
   constexpr int E = 16 / sizeof(T), ES = sizeof(T);
   constexpr int BKP = WgradCfg<T>::BKP, PAD = WgradCfg<T>::PAD;
   constexpr int BNW = NCT * 16;
@@ -447,10 +448,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dy, co
   int* taptab = reinterpret_cast<int*>(Xs + BKP * PX);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cd0 = blockIdx.x * BMW, col0 = blockIdx.y * BNW;
+  // XCD-aware order (workgroups b and b+8 share an L2): XCD x takes the x-th contiguous eighth of the tiles in
+  // (row tile, pixel slice, column tile) order, so an L2 holds ONE channel slice of dy (deep layers: Cd/64 >= 8 row
+  // tiles) or ONE band of pixels (shallow layers: many pixel slices) instead of a sample of the whole layer.  Measured
+  // before: 64 MB of fabric reads per launch for 25 MB algorithmic (profiles/r01/d_pmc_traffic.json).
+  const int chunk = gridDim.x >> 3;
+  const int tix = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tix >= gx * gy * gz) return;
+  const int bx = tix / (gz * gy), bz = (tix / gy) % gz, by = tix % gy;
+  const int cd0 = bx * BMW, col0 = by * BNW;
   const int ncols = g.ntaps * g.Cs;
   const int HWm = g.Hm * g.Wm;
-  const int p_begin = blockIdx.z * pps, p_end = min(P, p_begin + pps);
+  const int p_begin = bz * pps, p_end = min(P, p_begin + pps);
   const __amdgpu_buffer_rsrc_t dyR = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t srcR = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, src_bytes, 0x00020000);
 #pragma unroll
@@ -602,8 +611,9 @@ int launch_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t&
   nsplit = (P + pps - 1) / pps;
   const unsigned dy_bytes = (unsigned)((size_t)P * g.Cd * sizeof(T));
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
-  hipLaunchKernelGGL((wgrad_kernel<T, BMW, NCT>), dim3(gx, gy, nsplit), dim3(256), LDS, s, (const T*)dy, (const T*)src, dw, g, P, pps,
-                     dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm);
+  const int total = gx * gy * nsplit;
+  hipLaunchKernelGGL((wgrad_kernel<T, BMW, NCT>), dim3((total + 7) / 8 * 8), dim3(256), LDS, s, (const T*)dy, (const T*)src, dw, g, P, pps,
+                     dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm, gx, gy, nsplit);
   AST_CHECK_LAUNCH();
   return 0;
 }
