@@ -22,3 +22,7 @@ fused_tokens = _os.environ.get("AST_FUSED_TOKENS", "1") != "0"
 # BatchNorm batch statistics accumulated in the producing conv GEMM's epilogue instead of a separate pass over its
 # output (AST_FUSED_BN_STATS=0 keeps the separate pass: the reference path for tests and A/B timing).
 fused_bn_stats = _os.environ.get("AST_FUSED_BN_STATS", "1") != "0"
+
+# BatchNorm/ResBlock-tail backward: recompute the ReLU mask from the pre-activation (x, scale, shift) instead of
+# reading the activation output (AST_BN_MASK_FROM_PREACT=0 reads y: the reference path for A/B timing).
+bn_mask_from_preact = _os.environ.get("AST_BN_MASK_FROM_PREACT", "1") != "0"

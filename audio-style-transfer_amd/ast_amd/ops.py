@@ -13,7 +13,7 @@ import math
 
 import torch
 
-from . import _lib
+from . import _lib, config
 from ._lib import Gather, check, dcode, lib, ptr, stream
 
 
@@ -569,21 +569,23 @@ class BatchNormActFn(torch.autograd.Function):
         y = torch.empty_like(x)
         check(lib().ast_affine_act(ptr(x), ptr(scale), ptr(shift), None, None, None, ptr(y), N, H * W, C, int(relu),
                                    dcode(x.dtype), stream()), "ast_affine_act")
-        ctx.save_for_backward(x, y, mean, rstd)
+        ctx.save_for_backward(x, y, mean, rstd, scale, shift)
         ctx.gamma, ctx.beta, ctx.relu, ctx.training = gamma, beta, relu, training
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, rstd = ctx.saved_tensors
+        x, y, mean, rstd, scale, shift = ctx.saved_tensors
+        pre = config.bn_mask_from_preact and ctx.relu          # ReLU mask recomputed from x: y is not read
         if not ctx.training:
             raise RuntimeError("BatchNormActFn: backward in eval mode is not on the reference's path")
         dy = dy.contiguous()
         N, H, W, C = x.shape
         gamma, beta = ctx.gamma, ctx.beta
         sums3 = _clean_scratch(N * C * 3, x.device)
-        check(lib().ast_norm_bwd_sums(ptr(dy), ptr(y), ptr(x), None, ptr(sums3), N, H * W, C, int(ctx.relu),
-                                      dcode(x.dtype), 1, stream()), "ast_norm_bwd_sums")
+        check(lib().ast_norm_bwd_sums_pre(ptr(dy), ptr(y), ptr(x), None, ptr(sums3), N, H * W, C, int(ctx.relu),
+                                          dcode(x.dtype), 1, ptr(scale) if pre else None, ptr(shift) if pre else None, None, None,
+                                          stream()), "ast_norm_bwd_sums")
         k1 = torch.empty((C, 3), dtype=torch.float32, device=x.device)
         gsum = _global_sums(sums3, N * C * 3) if _SyncBN.world > 1 else None
         # gamma/beta gradients come from the LOCAL sums (the gradient all-reduce averages them over ranks)
@@ -594,8 +596,9 @@ class BatchNormActFn(torch.autograd.Function):
             check(lib().ast_norm_bwd_finalize(ptr(gsum), 0, N, H * W * _SyncBN.world, C, gamma.numel(), ptr(gamma), ptr(mean), ptr(rstd),
                                               None, None, ptr(k1), None, None, None, None, None, None, stream()), "ast_norm_bwd_finalize")
         dx = torch.empty_like(x)
-        check(lib().ast_norm_bwd_apply(ptr(dy), ptr(y), ptr(x), None, ptr(k1), None, ptr(dx), None, N, H * W, C,
-                                       int(ctx.relu), dcode(x.dtype), stream()), "ast_norm_bwd_apply")
+        check(lib().ast_norm_bwd_apply_pre(ptr(dy), ptr(y), ptr(x), None, ptr(k1), None, ptr(dx), None, N, H * W, C,
+                                           int(ctx.relu), dcode(x.dtype), ptr(scale) if pre else None, ptr(shift) if pre else None,
+                                           None, None, stream()), "ast_norm_bwd_apply")
         return dx, None, None, None, None, None, None
 
 
@@ -616,13 +619,14 @@ class ResTailFn(torch.autograd.Function):
         y = torch.empty_like(c2)
         check(lib().ast_affine_act(ptr(c2), ptr(s1), ptr(f1), ptr(ds), ptr(s2), ptr(f2), ptr(y), N, H * W, C, 1,
                                    dcode(c2.dtype), stream()), "ast_affine_act")
-        ctx.save_for_backward(c2, ds, y, m1, r1, m2, r2)
+        ctx.save_for_backward(c2, ds, y, m1, r1, m2, r2, s1, f1, s2, f2)
         ctx.params, ctx.training = (g1, b1, g2, b2), training
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        c2, ds, y, m1, r1, m2, r2 = ctx.saved_tensors
+        c2, ds, y, m1, r1, m2, r2, s1, f1, s2, f2 = ctx.saved_tensors
+        pre = config.bn_mask_from_preact
         if not ctx.training:
             raise RuntimeError("ResTailFn: backward in eval mode is not on the reference's path")
         g1, b1, g2, b2 = ctx.params
@@ -630,8 +634,9 @@ class ResTailFn(torch.autograd.Function):
         N, H, W, C = c2.shape
         dev = c2.device
         sums3 = _clean_scratch(N * C * 3, dev)
-        check(lib().ast_norm_bwd_sums(ptr(dy), ptr(y), ptr(c2), ptr(ds), ptr(sums3), N, H * W, C, 1, dcode(c2.dtype),
-                                      1, stream()), "ast_norm_bwd_sums")
+        coef = (ptr(s1), ptr(f1), ptr(s2), ptr(f2)) if pre else (None, None, None, None)
+        check(lib().ast_norm_bwd_sums_pre(ptr(dy), ptr(y), ptr(c2), ptr(ds), ptr(sums3), N, H * W, C, 1, dcode(c2.dtype),
+                                          1, *coef, stream()), "ast_norm_bwd_sums")
         k1 = torch.empty((C, 3), dtype=torch.float32, device=dev)
         k2 = torch.empty((N, C, 3), dtype=torch.float32, device=dev)
         gsum = _global_sums(sums3, N * C * 3) if _SyncBN.world > 1 else None
@@ -643,8 +648,8 @@ class ResTailFn(torch.autograd.Function):
             check(lib().ast_norm_bwd_finalize(ptr(gsum), 0, N, H * W * _SyncBN.world, C, g1.numel(), ptr(g1), ptr(m1), ptr(r1),
                                               None, None, ptr(k1), None, None, None, None, None, None, stream()), "ast_norm_bwd_finalize")
         dc2, dds = torch.empty_like(c2), torch.empty_like(ds)
-        check(lib().ast_norm_bwd_apply(ptr(dy), ptr(y), ptr(c2), ptr(ds), ptr(k1), ptr(k2), ptr(dc2), ptr(dds), N, H * W,
-                                       C, 1, dcode(c2.dtype), stream()), "ast_norm_bwd_apply")
+        check(lib().ast_norm_bwd_apply_pre(ptr(dy), ptr(y), ptr(c2), ptr(ds), ptr(k1), ptr(k2), ptr(dc2), ptr(dds), N, H * W,
+                                           C, 1, dcode(c2.dtype), *coef, stream()), "ast_norm_bwd_apply")
         return dc2, dds, None, None, None, None, None, None, None, None
 
 

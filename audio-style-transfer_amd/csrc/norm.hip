@@ -15,7 +15,11 @@ namespace {
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                            const T* __restrict__ c, const T* __restrict__ d,
-                                                           float* __restrict__ sums, int HW, int C, int ppb, int relu) {
+                                                           float* __restrict__ sums, int HW, int C, int ppb, int relu,
+                                                           const float* __restrict__ sc1, const float* __restrict__ sf1,
+                                                           const float* __restrict__ sc2, const float* __restrict__ sf2) {
+  // MODE 1 with sc1 != null: the ReLU mask is recomputed from the pre-activation fma(x, sc1, sf1) [+ fma(r, sc2[n], sf2[n])]
+  // exactly as affine_act_kernel formed it, so the activation output `b` is not read at all (one third of the traffic)
   constexpr int K = MODE == 0 ? 2 : 3;
   __shared__ float red[256 * 8];
   const int U = C >> 3;
@@ -38,20 +42,34 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const T* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s[0][i] += va[i]; s[1][i] += va[i] * va[i]; }
       } else {
-        float vx[8];
+        float vx[8], vr[8];
+        U8<T>::load(c + off, vx);
+        if (d) U8<T>::load(d + off, vr);
         if (relu) {
           float vy[8];
-          U8<T>::load(b + off, vy);
+          if (sc1) {
+            float a1[8], b1[8];
+            U8<float>::load(sc1 + u * 8, a1);
+            U8<float>::load(sf1 + u * 8, b1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vy[i] = __builtin_fmaf(vx[i], a1[i], b1[i]);
+            if (d) {
+              U8<float>::load(sc2 + (size_t)n * C + u * 8, a1);
+              U8<float>::load(sf2 + (size_t)n * C + u * 8, b1);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) vy[i] += __builtin_fmaf(vr[i], a1[i], b1[i]);
+            }
+          } else {
+            U8<T>::load(b + off, vy);
+          }
 #pragma unroll
           for (int i = 0; i < 8; ++i) va[i] = vy[i] > 0.f ? va[i] : 0.f;
         }
-        U8<T>::load(c + off, vx);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s[0][i] += va[i]; s[1][i] += va[i] * vx[i]; }
         if (d) {
-          U8<T>::load(d + off, vx);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) s[2][i] += va[i] * vx[i];
+          for (int i = 0; i < 8; ++i) s[2][i] += va[i] * vr[i];
         }
       }
     }
@@ -139,14 +157,14 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
     U8<float>::load(scale + cidx, sc);
     U8<float>::load(shift + cidx, sf);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = v[k] * sc[k] + sf[k];
+    for (int k = 0; k < 8; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sf[k]);
     if (r) {
       float w[8];
       U8<T>::load(r + i * 8, w);
       U8<float>::load(scale2 + (size_t)n * C + u * 8, sc);
       U8<float>::load(shift2 + (size_t)n * C + u * 8, sf);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] += w[k] * sc[k] + sf[k];
+      for (int k = 0; k < 8; ++k) v[k] += __builtin_fmaf(w[k], sc[k], sf[k]);
     }
     if (relu) {
 #pragma unroll
@@ -206,22 +224,41 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                               const T* __restrict__ x, const T* __restrict__ r,
                                                               const float* __restrict__ k1, const float* __restrict__ k2,
                                                               T* __restrict__ dx, T* __restrict__ dr, int HW, int C,
-                                                              size_t units, int relu) {
+                                                              size_t units, int relu, const float* __restrict__ sc1,
+                                                              const float* __restrict__ sf1, const float* __restrict__ sc2,
+                                                              const float* __restrict__ sf2) {
   const int U = C >> 3;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (size_t)gridDim.x * blockDim.x) {
     const int u = (int)(i % U);
     const size_t pix = i / U;
     const int n = (int)(pix / HW);
-    float dz[8], v[8], o[8];
+    float dz[8], v[8], o[8], vr[8];
     U8<T>::load(dy + i * 8, dz);
+    const bool remask = relu && sc1;           // mask from the pre-activation (see chan_reduce_kernel): y is not read
+    if (remask || (dx && k1)) U8<T>::load(x + i * 8, v);
+    if (dr || (remask && r)) U8<T>::load(r + i * 8, vr);
     if (relu) {
-      U8<T>::load(y + i * 8, v);
+      float pre[8];
+      if (remask) {
+        float a1[8], b1[8];
+        U8<float>::load(sc1 + u * 8, a1);
+        U8<float>::load(sf1 + u * 8, b1);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) dz[k] = v[k] > 0.f ? dz[k] : 0.f;
+        for (int k = 0; k < 8; ++k) pre[k] = __builtin_fmaf(v[k], a1[k], b1[k]);
+        if (r) {
+          U8<float>::load(sc2 + (size_t)n * C + u * 8, a1);
+          U8<float>::load(sf2 + (size_t)n * C + u * 8, b1);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) pre[k] += __builtin_fmaf(vr[k], a1[k], b1[k]);
+        }
+      } else {
+        U8<T>::load(y + i * 8, pre);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dz[k] = pre[k] > 0.f ? dz[k] : 0.f;
     }
     if (dx) {
       if (k1) {
-        U8<T>::load(x + i * 8, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float* kk = k1 + (u * 8 + k) * 3;
@@ -233,11 +270,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
       }
     }
     if (dr) {
-      U8<T>::load(r + i * 8, v);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float* kk = k2 + ((size_t)n * C + u * 8 + k) * 3;
-        o[k] = kk[0] * dz[k] + kk[1] * v[k] + kk[2];
+        o[k] = kk[0] * dz[k] + kk[1] * vr[k] + kk[2];
       }
       U8<T>::store(dr + i * 8, o);
     }
@@ -358,8 +394,9 @@ extern "C" int ast_chan_stats(const void* x, float* sums, int N, int HW, int C, 
   const int nblk = max(1, min((HW + PL - 1) / PL, max(1, 2048 / N)));
   const int ppb = (HW + nblk - 1) / nblk;
   dim3 grid((HW + ppb - 1) / ppb, N);
+  const float* nf = nullptr;
   AST_DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 0>), grid, dim3(256), 0, s, (const T*)x, (const T*)nullptr,
-                                            (const T*)nullptr, (const T*)nullptr, sums, HW, C, ppb, 0));
+                                            (const T*)nullptr, (const T*)nullptr, sums, HW, C, ppb, 0, nf, nf, nf, nf));
   AST_CHECK_LAUNCH();
   return 0;
 }
@@ -391,9 +428,11 @@ extern "C" int ast_affine_act(const void* x, const float* scale, const float* sh
   return 0;
 }
 
-extern "C" int ast_norm_bwd_sums(const void* dy, const void* y, const void* x, const void* r, float* sums3, int N, int HW,
-                                 int C, int relu, int dtype, int assume_zeroed, void* stream) {
-  if (!dy || !x || !sums3 || (relu && !y) || (C & 7) || C > 2048) AST_FAIL("ast_norm_bwd_sums: bad args");
+extern "C" int ast_norm_bwd_sums_pre(const void* dy, const void* y, const void* x, const void* r, float* sums3, int N, int HW,
+                                     int C, int relu, int dtype, int assume_zeroed, const float* scale1, const float* shift1,
+                                     const float* scale2, const float* shift2, void* stream) {
+  if (!dy || !x || !sums3 || (relu && !y && !scale1) || (C & 7) || C > 2048) AST_FAIL("ast_norm_bwd_sums: bad args");
+  if (scale1 && (!shift1 || (r && (!scale2 || !shift2)))) AST_FAIL("ast_norm_bwd_sums: incomplete pre-activation coefficients");
   hipStream_t s = (hipStream_t)stream;
   if (!assume_zeroed) AST_HIP(hipMemsetAsync(sums3, 0, sizeof(float) * (size_t)N * C * 3, s));
   const int PL = 256 / (C >> 3);
@@ -401,9 +440,14 @@ extern "C" int ast_norm_bwd_sums(const void* dy, const void* y, const void* x, c
   const int ppb = (HW + nblk - 1) / nblk;
   dim3 grid((HW + ppb - 1) / ppb, N);
   AST_DISPATCH_T(dtype, hipLaunchKernelGGL((chan_reduce_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)dy, (const T*)y,
-                                            (const T*)x, (const T*)r, sums3, HW, C, ppb, relu));
+                                            (const T*)x, (const T*)r, sums3, HW, C, ppb, relu, scale1, shift1, scale2, shift2));
   AST_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int ast_norm_bwd_sums(const void* dy, const void* y, const void* x, const void* r, float* sums3, int N, int HW,
+                                 int C, int relu, int dtype, int assume_zeroed, void* stream) {
+  return ast_norm_bwd_sums_pre(dy, y, x, r, sums3, N, HW, C, relu, dtype, assume_zeroed, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int ast_norm_bwd_finalize(float* sums3, int zero_sums, int N, int HW, int C, int Creal, const float* gamma1,
@@ -417,16 +461,24 @@ extern "C" int ast_norm_bwd_finalize(float* sums3, int zero_sums, int N, int HW,
   return 0;
 }
 
-extern "C" int ast_norm_bwd_apply(const void* dy, const void* y, const void* x, const void* r, const float* k1,
-                                  const float* k2, void* dx, void* dr, int N, int HW, int C, int relu, int dtype,
-                                  void* stream) {
-  if (!dy || (relu && !y) || (dx && k1 && !x) || (dr && (!r || !k2)) || (C & 7)) AST_FAIL("ast_norm_bwd_apply: bad args");
+extern "C" int ast_norm_bwd_apply_pre(const void* dy, const void* y, const void* x, const void* r, const float* k1,
+                                      const float* k2, void* dx, void* dr, int N, int HW, int C, int relu, int dtype,
+                                      const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                                      void* stream) {
+  if (!dy || (relu && !y && !scale1) || (dx && k1 && !x) || (dr && (!r || !k2)) || (C & 7)) AST_FAIL("ast_norm_bwd_apply: bad args");
+  if (scale1 && (!x || !shift1 || (r && (!scale2 || !shift2)))) AST_FAIL("ast_norm_bwd_apply: incomplete pre-activation coefficients");
   const size_t units = (size_t)N * HW * (C >> 3);
   AST_DISPATCH_T(dtype, hipLaunchKernelGGL((norm_bwd_apply_kernel<T>), dim3(grid_for(units)), dim3(256), 0,
                                             (hipStream_t)stream, (const T*)dy, (const T*)y, (const T*)x, (const T*)r, k1, k2,
-                                            (T*)dx, (T*)dr, HW, C, units, relu));
+                                            (T*)dx, (T*)dr, HW, C, units, relu, scale1, shift1, scale2, shift2));
   AST_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int ast_norm_bwd_apply(const void* dy, const void* y, const void* x, const void* r, const float* k1,
+                                  const float* k2, void* dx, void* dr, int N, int HW, int C, int relu, int dtype,
+                                  void* stream) {
+  return ast_norm_bwd_apply_pre(dy, y, x, r, k1, k2, dx, dr, N, HW, C, relu, dtype, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int ast_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,

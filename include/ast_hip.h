@@ -172,6 +172,16 @@ int ast_norm_bwd_finalize(float* sums3, int zero_sums, int N, int HW, int C, int
 int ast_norm_bwd_apply(const void* dy, const void* y, const void* x, const void* r,
                        const float* k1, const float* k2, void* dx, void* dr,
                        int N, int HW, int C, int relu, int dtype, void* stream);
+/* The same two passes with the ReLU mask RECOMPUTED from the pre-activation fma(x, scale1[c], shift1[c])
+ * [+ fma(r, scale2[n][c], shift2[n][c])] -- bit-identical to what ast_affine_act formed in the forward pass -- so the
+ * activation output y is not read (a third of each pass's HBM traffic); y may be NULL when scale1 is given. */
+int ast_norm_bwd_sums_pre(const void* dy, const void* y, const void* x, const void* r, float* sums3, int N, int HW,
+                          int C, int relu, int dtype, int assume_zeroed, const float* scale1, const float* shift1,
+                          const float* scale2, const float* shift2, void* stream);
+int ast_norm_bwd_apply_pre(const void* dy, const void* y, const void* x, const void* r, const float* k1,
+                           const float* k2, void* dx, void* dr, int N, int HW, int C, int relu, int dtype,
+                           const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                           void* stream);
 
 int ast_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                       float* rstd, int rows, int D, float eps, int dtype, void* stream);
