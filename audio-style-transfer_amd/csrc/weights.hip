@@ -3,6 +3,7 @@
 // GEMM layouts, batched over ALL weights of a model in three launches
 // (launch boundaries act as the grid-wide syncs between v, u and sigma), and
 // the matching backward:  dW_orig = (dW - <dW, W/sigma> u v^T) / sigma.
+#include <type_traits>
 #include "ast_common.h"
 #include "../../include/ast_hip.h"
 
@@ -112,38 +113,43 @@ constexpr int TL = 32;                       // tile edge (channels)
 constexpr int LP = TL + 1;                   // LDS pitch of the [tap][co][ci] image (floats)
 
 // L[tap][co_l][ci_l] <- master w (coalesced along the master's contiguous dimension)
+// KKC = compile-time tap count (1 and 9 cover every weight of the model: the index arithmetic of these loops is a
+// division by KK per element, ~40 VALU each with a run-time divisor); KKC = 0 keeps the run-time form.
+template <int KKC>
 __device__ __forceinline__ void tile_load_master(const ast_weight_desc_t& d, const float* __restrict__ base, int co0, int ci0,
                                                  float* __restrict__ L, float scale) {
+  const int KK = KKC > 0 ? KKC : d.KK;
   const bool co_outer = d.s_co >= d.s_ci;    // conv: [co][ci][tap];  convT: [ci][co][tap]
-  const int run = TL * d.KK;                 // contiguous floats per outer index (inner channel x tap)
+  const int run = TL * KK;                   // contiguous floats per outer index (inner channel x tap)
   for (int idx = threadIdx.x; idx < TL * run; idx += 256) {
     const int o = idx / run, r = idx - o * run;
-    const int in = r / d.KK, tap = r - in * d.KK;
+    const int in = r / KK, tap = r - in * KK;
     const int co = co_outer ? co0 + o : co0 + in, ci = co_outer ? ci0 + in : ci0 + o;
     const float v = (co < d.Co && ci < d.Ci) ? base[(size_t)co * d.s_co + (size_t)ci * d.s_ci + tap] * scale : 0.f;
     L[(tap * TL + (co - co0)) * LP + (ci - ci0)] = v;
   }
 }
 
-template <typename T>
+template <typename T, int KKC>
 __device__ __forceinline__ void tile_store_packed(const ast_weight_desc_t& d, int co0, int ci0, const float* __restrict__ L) {
+  const int KK = KKC > 0 ? KKC : d.KK;
   // wf[(co*KK + tap)*Cip + ci]: rows (co_l, tap), 32 ci each
   if (d.wf) {
     T* wf = (T*)d.wf;
-    for (int idx = threadIdx.x; idx < TL * d.KK * TL; idx += 256) {
+    for (int idx = threadIdx.x; idx < TL * KK * TL; idx += 256) {
       const int ci_l = idx & (TL - 1), row = idx >> 5;
-      const int tap = row % d.KK, co_l = row / d.KK;
+      const int co_l = row / KK, tap = row - co_l * KK;
       const int co = co0 + co_l, ci = ci0 + ci_l;
-      if (co < d.Cop && ci < d.Cip) wf[((size_t)co * d.KK + tap) * d.Cip + ci] = (T)L[(tap * TL + co_l) * LP + ci_l];
+      if (co < d.Cop && ci < d.Cip) wf[((size_t)co * KK + tap) * d.Cip + ci] = (T)L[(tap * TL + co_l) * LP + ci_l];
     }
   }
   if (d.wb) {
     T* wb = (T*)d.wb;
-    for (int idx = threadIdx.x; idx < TL * d.KK * TL; idx += 256) {
+    for (int idx = threadIdx.x; idx < TL * KK * TL; idx += 256) {
       const int co_l = idx & (TL - 1), row = idx >> 5;
-      const int tap = row % d.KK, ci_l = row / d.KK;
+      const int ci_l = row / KK, tap = row - ci_l * KK;
       const int co = co0 + co_l, ci = ci0 + ci_l;
-      if (co < d.Cop && ci < d.Cip) wb[((size_t)ci * d.KK + tap) * d.Cop + co] = (T)L[(tap * TL + co_l) * LP + ci_l];
+      if (co < d.Cop && ci < d.Cip) wb[((size_t)ci * KK + tap) * d.Cop + co] = (T)L[(tap * TL + co_l) * LP + ci_l];
     }
   }
 }
@@ -172,33 +178,44 @@ __global__ __launch_bounds__(256) void sn_sigma_kernel(const ast_weight_desc_t* 
   for (int j = threadIdx.x; j < d.Ci * d.KK; j += 256) d.scratch[d.Co + j] = 0.f;   // t = W^T u zeroed for the next forward's atomics
 }
 
+template <int KKC>
+__device__ __forceinline__ void pack_tile_body(const ast_weight_desc_t& d, const WTile& tl, int dtype, float* __restrict__ L) {
+  const int KK = KKC > 0 ? KKC : d.KK;
+  tile_load_master<KKC>(d, d.w, tl.co0, tl.ci0, L, 1.f / d.sigma[0]);
+  __syncthreads();
+  if (dtype == AST_BF16) tile_store_packed<bf16_t, KKC>(d, tl.co0, tl.ci0, L); else tile_store_packed<float, KKC>(d, tl.co0, tl.ci0, L);
+  if (d.dwp && d.power_iter) {                // fresh gradient staging for this step (this tile's slice, both layouts cover it once)
+    for (int idx = threadIdx.x; idx < TL * KK * TL; idx += 256) {
+      const int in_l = idx & (TL - 1), row = idx >> 5;
+      const int out_l = row / KK, tap = row - out_l * KK;
+      if (d.dwp_from_wb) { const int ci = tl.ci0 + out_l, co = tl.co0 + in_l; if (ci < d.Cip && co < d.Cop) d.dwp[((size_t)ci * KK + tap) * d.Cop + co] = 0.f; }
+      else { const int co = tl.co0 + out_l, ci = tl.ci0 + in_l; if (co < d.Cop && ci < d.Cip) d.dwp[((size_t)co * KK + tap) * d.Cip + ci] = 0.f; }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_tiles_kernel(const ast_weight_desc_t* __restrict__ descs, const int* __restrict__ dtypes,
                                                           const WTile* __restrict__ tiles) {
   __shared__ float L[9 * TL * LP];
   const WTile tl = tiles[blockIdx.x];
   const ast_weight_desc_t d = descs[tl.w];
-  tile_load_master(d, d.w, tl.co0, tl.ci0, L, 1.f / d.sigma[0]);
-  __syncthreads();
-  if (dtypes[tl.w] == AST_BF16) tile_store_packed<bf16_t>(d, tl.co0, tl.ci0, L); else tile_store_packed<float>(d, tl.co0, tl.ci0, L);
-  if (d.dwp && d.power_iter) {                // fresh gradient staging for this step (this tile's slice, both layouts cover it once)
-    for (int idx = threadIdx.x; idx < TL * d.KK * TL; idx += 256) {
-      const int in_l = idx & (TL - 1), row = idx >> 5;
-      const int tap = row % d.KK, out_l = row / d.KK;
-      if (d.dwp_from_wb) { const int ci = tl.ci0 + out_l, co = tl.co0 + in_l; if (ci < d.Cip && co < d.Cop) d.dwp[((size_t)ci * d.KK + tap) * d.Cop + co] = 0.f; }
-      else { const int co = tl.co0 + out_l, ci = tl.ci0 + in_l; if (co < d.Cop && ci < d.Cip) d.dwp[((size_t)co * d.KK + tap) * d.Cip + ci] = 0.f; }
-    }
-  }
+  const int dt = dtypes[tl.w];
+  if (d.KK == 9) pack_tile_body<9>(d, tl, dt, L);
+  else if (d.KK == 1) pack_tile_body<1>(d, tl, dt, L);
+  else pack_tile_body<0>(d, tl, dt, L);
 }
 
 // G[tap][co_l][ci_l] <- packed gradient staging (coalesced along its contiguous channel dimension)
+template <int KKC>
 __device__ __forceinline__ void tile_load_dwp(const ast_weight_desc_t& d, int co0, int ci0, float* __restrict__ G) {
-  for (int idx = threadIdx.x; idx < TL * d.KK * TL; idx += 256) {
+  const int KK = KKC > 0 ? KKC : d.KK;
+  for (int idx = threadIdx.x; idx < TL * KK * TL; idx += 256) {
     const int in_l = idx & (TL - 1), row = idx >> 5;
-    const int tap = row % d.KK, out_l = row / d.KK;
+    const int out_l = row / KK, tap = row - out_l * KK;
     float v = 0.f;
     int co_l, ci_l;
-    if (d.dwp_from_wb) { ci_l = out_l; co_l = in_l; const int ci = ci0 + ci_l, co = co0 + co_l; if (ci < d.Ci && co < d.Co) v = d.dwp[((size_t)ci * d.KK + tap) * d.Cop + co]; }
-    else { co_l = out_l; ci_l = in_l; const int co = co0 + co_l, ci = ci0 + ci_l; if (co < d.Co && ci < d.Ci) v = d.dwp[((size_t)co * d.KK + tap) * d.Cip + ci]; }
+    if (d.dwp_from_wb) { ci_l = out_l; co_l = in_l; const int ci = ci0 + ci_l, co = co0 + co_l; if (ci < d.Ci && co < d.Co) v = d.dwp[((size_t)ci * KK + tap) * d.Cop + co]; }
+    else { co_l = out_l; ci_l = in_l; const int co = co0 + co_l, ci = ci0 + ci_l; if (co < d.Co && ci < d.Ci) v = d.dwp[((size_t)co * KK + tap) * d.Cip + ci]; }
     G[(tap * TL + co_l) * LP + ci_l] = v;
   }
 }
@@ -209,19 +226,26 @@ __global__ __launch_bounds__(256) void flush_inner_tiles_kernel(const ast_weight
   const WTile tl = tiles[blockIdx.x];
   const ast_weight_desc_t d = descs[tl.w];
   if (!d.dwp || !d.u) return;
-  tile_load_dwp(d, tl.co0, tl.ci0, G);
-  __syncthreads();
-  // walk the master in ITS contiguous order and pick the matching staged gradient from LDS
-  const bool co_outer = d.s_co >= d.s_ci;
-  const int run = TL * d.KK;
   float q = 0.f;
-  for (int idx = threadIdx.x; idx < TL * run; idx += 256) {
-    const int o = idx / run, r = idx - o * run;
-    const int in = r / d.KK, tap = r - in * d.KK;
-    const int co_l = co_outer ? o : in, ci_l = co_outer ? in : o;
-    const int co = tl.co0 + co_l, ci = tl.ci0 + ci_l;
-    if (co < d.Co && ci < d.Ci) q += G[(tap * TL + co_l) * LP + ci_l] * d.w[(size_t)co * d.s_co + (size_t)ci * d.s_ci + tap];
-  }
+  auto body = [&](auto kkc) __attribute__((always_inline)) {
+    constexpr int KKC = decltype(kkc)::value;
+    const int KK = KKC > 0 ? KKC : d.KK;
+    tile_load_dwp<KKC>(d, tl.co0, tl.ci0, G);
+    __syncthreads();
+    // walk the master in ITS contiguous order and pick the matching staged gradient from LDS
+    const bool co_outer = d.s_co >= d.s_ci;
+    const int run = TL * KK;
+    for (int idx = threadIdx.x; idx < TL * run; idx += 256) {
+      const int o = idx / run, r = idx - o * run;
+      const int in = r / KK, tap = r - in * KK;
+      const int co_l = co_outer ? o : in, ci_l = co_outer ? in : o;
+      const int co = tl.co0 + co_l, ci = tl.ci0 + ci_l;
+      if (co < d.Co && ci < d.Ci) q += G[(tap * TL + co_l) * LP + ci_l] * d.w[(size_t)co * d.s_co + (size_t)ci * d.s_ci + tap];
+    }
+  };
+  if (d.KK == 9) body(std::integral_constant<int, 9>{});
+  else if (d.KK == 1) body(std::integral_constant<int, 1>{});
+  else body(std::integral_constant<int, 0>{});
   q = block_sum(q, red);
   if (threadIdx.x == 0 && q != 0.f) unsafeAtomicAdd(d.inner, q / d.sigma[0]);
 }
@@ -231,23 +255,30 @@ __global__ __launch_bounds__(256) void flush_unpack_tiles_kernel(const ast_weigh
   const WTile tl = tiles[blockIdx.x];
   const ast_weight_desc_t d = descs[tl.w];
   if (!d.dwp || !d.grad) return;
-  tile_load_dwp(d, tl.co0, tl.ci0, G);
-  __syncthreads();
   const float inner = d.u ? d.inner[0] : 0.f;
   const float inv_sigma = d.u ? 1.f / d.sigma[0] : 1.f;
-  const bool co_outer = d.s_co >= d.s_ci;
-  const int run = TL * d.KK;
-  for (int idx = threadIdx.x; idx < TL * run; idx += 256) {
-    const int o = idx / run, r = idx - o * run;
-    const int in = r / d.KK, tap = r - in * d.KK;
-    const int co_l = co_outer ? o : in, ci_l = co_outer ? in : o;
-    const int co = tl.co0 + co_l, ci = tl.ci0 + ci_l;
-    if (co < d.Co && ci < d.Ci) {
-      float gv = G[(tap * TL + co_l) * LP + ci_l];
-      if (d.u) gv = (gv - inner * d.u[co] * d.v[ci * d.KK + tap]) * inv_sigma;
-      d.grad[(size_t)co * d.s_co + (size_t)ci * d.s_ci + tap] += gv;
+  auto body = [&](auto kkc) __attribute__((always_inline)) {
+    constexpr int KKC = decltype(kkc)::value;
+    const int KK = KKC > 0 ? KKC : d.KK;
+    tile_load_dwp<KKC>(d, tl.co0, tl.ci0, G);
+    __syncthreads();
+    const bool co_outer = d.s_co >= d.s_ci;
+    const int run = TL * KK;
+    for (int idx = threadIdx.x; idx < TL * run; idx += 256) {
+      const int o = idx / run, r = idx - o * run;
+      const int in = r / KK, tap = r - in * KK;
+      const int co_l = co_outer ? o : in, ci_l = co_outer ? in : o;
+      const int co = tl.co0 + co_l, ci = tl.ci0 + ci_l;
+      if (co < d.Co && ci < d.Ci) {
+        float gv = G[(tap * TL + co_l) * LP + ci_l];
+        if (d.u) gv = (gv - inner * d.u[co] * d.v[ci * KK + tap]) * inv_sigma;
+        d.grad[(size_t)co * d.s_co + (size_t)ci * d.s_ci + tap] += gv;
+      }
     }
-  }
+  };
+  if (d.KK == 9) body(std::integral_constant<int, 9>{});
+  else if (d.KK == 1) body(std::integral_constant<int, 1>{});
+  else body(std::integral_constant<int, 0>{});
 }
 }  // namespace
 
