@@ -53,9 +53,20 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const ast_weight_desc_t* __
   const int row = row0 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row < d.Co) {
     float acc = 0.f;
-    for (int j = lane; j < ncols; j += 64) {
-      const int ci = j / d.KK, tap = j - ci * d.KK;
-      acc += d.w[woff(d, row, ci, tap)] * vec[j];
+    if (d.s_ci == d.KK && (ncols & 3) == 0 && (d.s_co & 3) == 0 && ((((uintptr_t)vec) | ((uintptr_t)d.w)) & 15) == 0) {
+      // Conv2d / Linear layout [co][ci][tap]: the row is contiguous in j -- 16-byte loads, no (ci, tap) split
+      // (the generic loop spends a run-time division per element)
+      const f32x4* wr = reinterpret_cast<const f32x4*>(d.w + (size_t)row * d.s_co);
+      const f32x4* vr = reinterpret_cast<const f32x4*>(vec);
+      for (int j4 = lane; j4 < (ncols >> 2); j4 += 64) {
+        const f32x4 a = wr[j4], b = vr[j4];
+        acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+      }
+    } else {
+      for (int j = lane; j < ncols; j += 64) {
+        const int ci = j / d.KK, tap = j - ci * d.KK;
+        acc += d.w[woff(d, row, ci, tap)] * vec[j];
+      }
     }
     acc = wave_sum(acc) * inv;
     if (lane == 0) d.scratch[row] = acc;
