@@ -16,16 +16,31 @@ __device__ __forceinline__ size_t woff(const ast_weight_desc_t& d, int co, int c
 // t[j] = sum_co W(co, j) u[co],  j = ci*KK + tap  -> scratch[Co + j]
 // rows are split over grid.z (RZ chunks) and summed with atomics; scratch[Co..] is zeroed by sn_sigma_kernel
 // of the previous forward (and at allocation), so the launch needs no memset.
-constexpr int RZ = 8;
+constexpr int RZ = 32;
 __global__ __launch_bounds__(256) void sn_wt_u_kernel(const ast_weight_desc_t* __restrict__ descs) {
   const ast_weight_desc_t d = descs[blockIdx.y];
   if (!d.u || !d.power_iter) return;
   const int ncols = d.Ci * d.KK;
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= ncols) return;
   const int rows_per = (d.Co + RZ - 1) / RZ;
   const int c0 = blockIdx.z * rows_per, c1 = min(d.Co, c0 + rows_per);
   if (c0 >= c1) return;
+  if (d.s_ci == d.KK && (ncols & 3) == 0 && (d.s_co & 3) == 0 && (((uintptr_t)d.w) & 15) == 0) {
+    // Conv2d / Linear layout: rows are contiguous in j -> each thread owns 4 columns (16-byte loads); the first
+    // quarter of the grid covers all columns, the rest exits
+    const int j4 = blockIdx.x * 256 + threadIdx.x;
+    if (j4 >= (ncols >> 2)) return;
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    for (int co = c0; co < c1; ++co) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(d.w + (size_t)co * d.s_co + j4 * 4);
+      const float uc = d.u[co];
+      acc4[0] += w4[0] * uc; acc4[1] += w4[1] * uc; acc4[2] += w4[2] * uc; acc4[3] += w4[3] * uc;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(d.scratch + d.Co + j4 * 4 + e, acc4[e]);
+    return;
+  }
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= ncols) return;
   const int ci = j / d.KK, tap = j - ci * d.KK;
   float acc = 0.f;
   for (int co = c0; co < c1; ++co) acc += d.w[woff(d, co, ci, tap)] * d.u[co];
@@ -123,6 +138,15 @@ struct WTile { int w, co0, ci0, pad; };
 constexpr int TL = 32;                       // tile edge (channels)
 constexpr int LP = TL + 1;                   // LDS pitch of the [tap][co][ci] image (floats)
 
+__device__ __forceinline__ bool tile_is_full(const ast_weight_desc_t& d, int co0, int ci0) {
+  return co0 + TL <= d.Co && ci0 + TL <= d.Ci;
+}
+// the inner (channel, tap) run of the master layout is contiguous and 16-byte aligned for every outer index
+__device__ __forceinline__ bool master_vec_ok(const ast_weight_desc_t& d, const float* base) {
+  const int inner = d.s_co >= d.s_ci ? d.s_ci : d.s_co, outer = d.s_co >= d.s_ci ? d.s_co : d.s_ci;
+  return inner == d.KK && (outer & 3) == 0 && (((uintptr_t)base) & 15) == 0;
+}
+
 // L[tap][co_l][ci_l] <- master w (coalesced along the master's contiguous dimension)
 // KKC = compile-time tap count (1 and 9 cover every weight of the model: the index arithmetic of these loops is a
 // division by KK per element, ~40 VALU each with a run-time divisor); KKC = 0 keeps the run-time form.
@@ -132,6 +156,23 @@ __device__ __forceinline__ void tile_load_master(const ast_weight_desc_t& d, con
   const int KK = KKC > 0 ? KKC : d.KK;
   const bool co_outer = d.s_co >= d.s_ci;    // conv: [co][ci][tap];  convT: [ci][co][tap]
   const int run = TL * KK;                   // contiguous floats per outer index (inner channel x tap)
+  if (KKC > 0 && tile_is_full(d, co0, ci0) && master_vec_ok(d, base)) {
+    // full tile: every outer index owns one 16-byte-aligned run of 32*KK floats -> float4 loads
+    const int run4 = run >> 2;
+    for (int idx = threadIdx.x; idx < TL * run4; idx += 256) {
+      const int o = idx / run4, r4 = idx - o * run4;
+      const size_t off = co_outer ? (size_t)(co0 + o) * d.s_co + (size_t)ci0 * d.s_ci : (size_t)(ci0 + o) * d.s_ci + (size_t)co0 * d.s_co;
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(base + off + r4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = r4 * 4 + e;
+        const int in = r / KK, tap = r - in * KK;
+        const int co_l = co_outer ? o : in, ci_l = co_outer ? in : o;
+        L[(tap * TL + co_l) * LP + ci_l] = v4[e] * scale;
+      }
+    }
+    return;
+  }
   for (int idx = threadIdx.x; idx < TL * run; idx += 256) {
     const int o = idx / run, r = idx - o * run;
     const int in = r / KK, tap = r - in * KK;
@@ -144,6 +185,26 @@ __device__ __forceinline__ void tile_load_master(const ast_weight_desc_t& d, con
 template <typename T, int KKC>
 __device__ __forceinline__ void tile_store_packed(const ast_weight_desc_t& d, int co0, int ci0, const float* __restrict__ L) {
   const int KK = KKC > 0 ? KKC : d.KK;
+  if (KKC > 0 && tile_is_full(d, co0, ci0) && (d.Cip & 7) == 0 && (d.Cop & 7) == 0) {
+    // full tile: each (channel, tap) row of 32 packed values is written as four 8-element vectors
+    for (int idx = threadIdx.x; idx < TL * KK * 4; idx += 256) {
+      const int q = idx & 3, row = idx >> 2;
+      const int out_l = row / KK, tap = row - out_l * KK;
+      if (d.wf) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = L[(tap * TL + out_l) * LP + q * 8 + e];
+        U8<T>::store((T*)d.wf + ((size_t)(co0 + out_l) * KK + tap) * d.Cip + ci0 + q * 8, v);
+      }
+      if (d.wb) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = L[(tap * TL + q * 8 + e) * LP + out_l];
+        U8<T>::store((T*)d.wb + ((size_t)(ci0 + out_l) * KK + tap) * d.Cop + co0 + q * 8, v);
+      }
+    }
+    return;
+  }
   // wf[(co*KK + tap)*Cip + ci]: rows (co_l, tap), 32 ci each
   if (d.wf) {
     T* wf = (T*)d.wf;
@@ -195,7 +256,15 @@ __device__ __forceinline__ void pack_tile_body(const ast_weight_desc_t& d, const
   tile_load_master<KKC>(d, d.w, tl.co0, tl.ci0, L, 1.f / d.sigma[0]);
   __syncthreads();
   if (dtype == AST_BF16) tile_store_packed<bf16_t, KKC>(d, tl.co0, tl.ci0, L); else tile_store_packed<float, KKC>(d, tl.co0, tl.ci0, L);
-  if (d.dwp && d.power_iter) {                // fresh gradient staging for this step (this tile's slice, both layouts cover it once)
+  if (d.dwp && d.power_iter && KKC > 0 && tile_is_full(d, tl.co0, tl.ci0) && (d.Cip & 3) == 0 && (d.Cop & 3) == 0) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int idx = threadIdx.x; idx < TL * KK * 8; idx += 256) {
+      const int q = idx & 7, row = idx >> 3;
+      const int out_l = row / KK, tap = row - out_l * KK;
+      float* p = d.dwp_from_wb ? d.dwp + ((size_t)(tl.ci0 + out_l) * KK + tap) * d.Cop + tl.co0 : d.dwp + ((size_t)(tl.co0 + out_l) * KK + tap) * d.Cip + tl.ci0;
+      *reinterpret_cast<f32x4*>(p + q * 4) = z;
+    }
+  } else if (d.dwp && d.power_iter) {         // fresh gradient staging for this step (this tile's slice, both layouts cover it once)
     for (int idx = threadIdx.x; idx < TL * KK * TL; idx += 256) {
       const int in_l = idx & (TL - 1), row = idx >> 5;
       const int out_l = row / KK, tap = row - out_l * KK;
@@ -220,6 +289,21 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const ast_weight_desc_t
 template <int KKC>
 __device__ __forceinline__ void tile_load_dwp(const ast_weight_desc_t& d, int co0, int ci0, float* __restrict__ G) {
   const int KK = KKC > 0 ? KKC : d.KK;
+  if (KKC > 0 && tile_is_full(d, co0, ci0) && (d.Cip & 3) == 0 && (d.Cop & 3) == 0) {
+    for (int idx = threadIdx.x; idx < TL * KK * 8; idx += 256) {
+      const int q = idx & 7, row = idx >> 3;
+      const int out_l = row / KK, tap = row - out_l * KK;
+      const float* p = d.dwp_from_wb ? d.dwp + ((size_t)(ci0 + out_l) * KK + tap) * d.Cop + co0 : d.dwp + ((size_t)(co0 + out_l) * KK + tap) * d.Cip + ci0;
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(p + q * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int in_l = q * 4 + e;
+        const int co_l = d.dwp_from_wb ? in_l : out_l, ci_l = d.dwp_from_wb ? out_l : in_l;
+        G[(tap * TL + co_l) * LP + ci_l] = v4[e];
+      }
+    }
+    return;
+  }
   for (int idx = threadIdx.x; idx < TL * KK * TL; idx += 256) {
     const int in_l = idx & (TL - 1), row = idx >> 5;
     const int out_l = row / KK, tap = row - out_l * KK;
@@ -246,6 +330,22 @@ __global__ __launch_bounds__(256) void flush_inner_tiles_kernel(const ast_weight
     // walk the master in ITS contiguous order and pick the matching staged gradient from LDS
     const bool co_outer = d.s_co >= d.s_ci;
     const int run = TL * KK;
+    if (KKC > 0 && tile_is_full(d, tl.co0, tl.ci0) && master_vec_ok(d, d.w)) {
+      const int run4 = run >> 2;
+      for (int idx = threadIdx.x; idx < TL * run4; idx += 256) {
+        const int o = idx / run4, r4 = idx - o * run4;
+        const size_t off = co_outer ? (size_t)(tl.co0 + o) * d.s_co + (size_t)tl.ci0 * d.s_ci : (size_t)(tl.ci0 + o) * d.s_ci + (size_t)tl.co0 * d.s_co;
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(d.w + off + r4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = r4 * 4 + e;
+          const int in = r / KK, tap = r - in * KK;
+          const int co_l = co_outer ? o : in, ci_l = co_outer ? in : o;
+          q += G[(tap * TL + co_l) * LP + ci_l] * w4[e];
+        }
+      }
+      return;
+    }
     for (int idx = threadIdx.x; idx < TL * run; idx += 256) {
       const int o = idx / run, r = idx - o * run;
       const int in = r / KK, tap = r - in * KK;
@@ -275,6 +375,26 @@ __global__ __launch_bounds__(256) void flush_unpack_tiles_kernel(const ast_weigh
     __syncthreads();
     const bool co_outer = d.s_co >= d.s_ci;
     const int run = TL * KK;
+    if (KKC > 0 && tile_is_full(d, tl.co0, tl.ci0) && master_vec_ok(d, d.grad)) {
+      const int run4 = run >> 2;
+      for (int idx = threadIdx.x; idx < TL * run4; idx += 256) {
+        const int o = idx / run4, r4 = idx - o * run4;
+        const size_t off = co_outer ? (size_t)(tl.co0 + o) * d.s_co + (size_t)tl.ci0 * d.s_ci : (size_t)(tl.ci0 + o) * d.s_ci + (size_t)tl.co0 * d.s_co;
+        f32x4* gp = reinterpret_cast<f32x4*>(d.grad + off + r4 * 4);
+        f32x4 g4 = *gp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = r4 * 4 + e;
+          const int in = r / KK, tap = r - in * KK;
+          const int co_l = co_outer ? o : in, ci_l = co_outer ? in : o;
+          float gv = G[(tap * TL + co_l) * LP + ci_l];
+          if (d.u) gv = (gv - inner * d.u[tl.co0 + co_l] * d.v[(tl.ci0 + ci_l) * KK + tap]) * inv_sigma;
+          g4[e] += gv;
+        }
+        *gp = g4;
+      }
+      return;
+    }
     for (int idx = threadIdx.x; idx < TL * run; idx += 256) {
       const int o = idx / run, r = idx - o * run;
       const int in = r / KK, tap = r - in * KK;
