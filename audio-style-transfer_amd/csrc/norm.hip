@@ -33,6 +33,16 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const T* __restrict__ 
   for (int k = 0; k < K; ++k)
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[k][i] = 0.f;
+  // per-channel / per-(n, channel) coefficients of the pre-activation: fixed for this thread (u, n), loaded once
+  float a1[8], b1[8], a2[8], b2[8];
+  if (MODE == 1 && relu && sc1 && pl < PL) {
+    U8<float>::load(sc1 + u * 8, a1);
+    U8<float>::load(sf1 + u * 8, b1);
+    if (d) {
+      U8<float>::load(sc2 + (size_t)n * C + u * 8, a2);
+      U8<float>::load(sf2 + (size_t)n * C + u * 8, b2);
+    }
+  }
   if (pl < PL) {
     for (int p = p0 + pl; p < p1; p += PL) {
       const size_t off = ((size_t)n * HW + p) * C + u * 8;
@@ -48,16 +58,11 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const T* __restrict__ 
         if (relu) {
           float vy[8];
           if (sc1) {
-            float a1[8], b1[8];
-            U8<float>::load(sc1 + u * 8, a1);
-            U8<float>::load(sf1 + u * 8, b1);
 #pragma unroll
             for (int i = 0; i < 8; ++i) vy[i] = __builtin_fmaf(vx[i], a1[i], b1[i]);
             if (d) {
-              U8<float>::load(sc2 + (size_t)n * C + u * 8, a1);
-              U8<float>::load(sf2 + (size_t)n * C + u * 8, b1);
 #pragma unroll
-              for (int i = 0; i < 8; ++i) vy[i] += __builtin_fmaf(vr[i], a1[i], b1[i]);
+              for (int i = 0; i < 8; ++i) vy[i] += __builtin_fmaf(vr[i], a2[i], b2[i]);
             }
           } else {
             U8<T>::load(b + off, vy);
@@ -141,30 +146,43 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(float* __restrict__ 
   shift[idx] = bt - m * gmm * r;
 }
 
+// grid = (blocks per image, N): a thread keeps one 8-channel unit u of one image n for its whole pixel loop (the
+// stride is a multiple of U whenever U divides 256), so every per-channel coefficient is loaded ONCE; with the
+// coefficient loads inside the loop these passes issued ~10 loads per 16 bytes of payload.
 template <typename T>
 __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const T* __restrict__ r,
                                                           const float* __restrict__ scale2, const float* __restrict__ shift2,
                                                           T* __restrict__ y, int HW, int C, size_t units, int s1_per_n, int relu) {
   const int U = C >> 3;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (size_t)gridDim.x * blockDim.x) {
-    const int u = (int)(i % U);
-    const size_t pix = i / U;
-    const int n = (int)(pix / HW);
-    float v[8], sc[8], sf[8];
-    U8<T>::load(x + i * 8, v);
+  const int n = blockIdx.y;
+  const size_t per_img = (size_t)HW * U, base = (size_t)n * per_img;
+  const size_t stride = (size_t)gridDim.x * 256;
+  const bool hoist = (256 % U) == 0;
+  float sc[8], sf[8], sc2[8], sf2[8];
+  auto coef = [&](int u) __attribute__((always_inline)) {
     const size_t cidx = (s1_per_n ? (size_t)n * C : 0) + u * 8;
     U8<float>::load(scale + cidx, sc);
     U8<float>::load(shift + cidx, sf);
+    if (r) {
+      U8<float>::load(scale2 + (size_t)n * C + u * 8, sc2);
+      U8<float>::load(shift2 + (size_t)n * C + u * 8, sf2);
+    }
+  };
+  const size_t j0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (hoist) coef((int)(j0 % U));
+  for (size_t j = j0; j < per_img; j += stride) {
+    if (!hoist) coef((int)(j % U));
+    const size_t i = base + j;
+    float v[8];
+    U8<T>::load(x + i * 8, v);
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sf[k]);
     if (r) {
       float w[8];
       U8<T>::load(r + i * 8, w);
-      U8<float>::load(scale2 + (size_t)n * C + u * 8, sc);
-      U8<float>::load(shift2 + (size_t)n * C + u * 8, sf);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] += __builtin_fmaf(w[k], sc[k], sf[k]);
+      for (int k = 0; k < 8; ++k) v[k] += __builtin_fmaf(w[k], sc2[k], sf2[k]);
     }
     if (relu) {
 #pragma unroll
@@ -228,28 +246,51 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                               const float* __restrict__ sf1, const float* __restrict__ sc2,
                                                               const float* __restrict__ sf2) {
   const int U = C >> 3;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (size_t)gridDim.x * blockDim.x) {
-    const int u = (int)(i % U);
-    const size_t pix = i / U;
-    const int n = (int)(pix / HW);
+  const int n = blockIdx.y;                       // grid = (blocks per image, N): see affine_act_kernel
+  const size_t per_img = (size_t)HW * U, base = (size_t)n * per_img;
+  const size_t stride = (size_t)gridDim.x * 256;
+  const bool hoist = (256 % U) == 0;
+  const bool remask = relu && sc1;               // mask from the pre-activation (see chan_reduce_kernel): y is not read
+  float a1[8], b1[8], a2[8], b2[8], ka[8][3], kb[8][3];
+  auto coef = [&](int u) __attribute__((always_inline)) {
+    if (remask) {
+      U8<float>::load(sc1 + u * 8, a1);
+      U8<float>::load(sf1 + u * 8, b1);
+      if (r) {
+        U8<float>::load(sc2 + (size_t)n * C + u * 8, a2);
+        U8<float>::load(sf2 + (size_t)n * C + u * 8, b2);
+      }
+    }
+    if (dx && k1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ka[k][q] = k1[(u * 8 + k) * 3 + q];
+    }
+    if (dr) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) kb[k][q] = k2[((size_t)n * C + u * 8 + k) * 3 + q];
+    }
+  };
+  const size_t j0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (hoist) coef((int)(j0 % U));
+  for (size_t j = j0; j < per_img; j += stride) {
+    if (!hoist) coef((int)(j % U));
+    const size_t i = base + j;
     float dz[8], v[8], o[8], vr[8];
     U8<T>::load(dy + i * 8, dz);
-    const bool remask = relu && sc1;           // mask from the pre-activation (see chan_reduce_kernel): y is not read
     if (remask || (dx && k1)) U8<T>::load(x + i * 8, v);
     if (dr || (remask && r)) U8<T>::load(r + i * 8, vr);
     if (relu) {
       float pre[8];
       if (remask) {
-        float a1[8], b1[8];
-        U8<float>::load(sc1 + u * 8, a1);
-        U8<float>::load(sf1 + u * 8, b1);
 #pragma unroll
         for (int k = 0; k < 8; ++k) pre[k] = __builtin_fmaf(v[k], a1[k], b1[k]);
         if (r) {
-          U8<float>::load(sc2 + (size_t)n * C + u * 8, a1);
-          U8<float>::load(sf2 + (size_t)n * C + u * 8, b1);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) pre[k] += __builtin_fmaf(vr[k], a1[k], b1[k]);
+          for (int k = 0; k < 8; ++k) pre[k] += __builtin_fmaf(vr[k], a2[k], b2[k]);
         }
       } else {
         U8<T>::load(y + i * 8, pre);
@@ -260,10 +301,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     if (dx) {
       if (k1) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float* kk = k1 + (u * 8 + k) * 3;
-          o[k] = kk[0] * dz[k] + kk[1] * v[k] + kk[2];
-        }
+        for (int k = 0; k < 8; ++k) o[k] = ka[k][0] * dz[k] + ka[k][1] * v[k] + ka[k][2];
         U8<T>::store(dx + i * 8, o);
       } else {
         U8<T>::store(dx + i * 8, dz);   // plain ReLU backward
@@ -271,10 +309,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     }
     if (dr) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float* kk = k2 + ((size_t)n * C + u * 8 + k) * 3;
-        o[k] = kk[0] * dz[k] + kk[1] * vr[k] + kk[2];
-      }
+      for (int k = 0; k < 8; ++k) o[k] = kb[k][0] * dz[k] + kb[k][1] * vr[k] + kb[k][2];
       U8<T>::store(dr + i * 8, o);
     }
   }
@@ -421,7 +456,8 @@ extern "C" int ast_affine_act(const void* x, const float* scale, const float* sh
   const size_t units = (size_t)N * HW * (C >> 3);
   // scale given per channel ([C]); the instance form ([N][C]) is requested with relu bit 2
   const int s1_per_n = (relu >> 1) & 1;
-  AST_DISPATCH_T(dtype, hipLaunchKernelGGL((affine_act_kernel<T>), dim3(grid_for(units)), dim3(256), 0, (hipStream_t)stream,
+  const dim3 agrid(std::max(1, std::min<int>((int)(((size_t)HW * (C >> 3) + 255) / 256), std::max(1, 4096 / N))), N);
+  AST_DISPATCH_T(dtype, hipLaunchKernelGGL((affine_act_kernel<T>), agrid, dim3(256), 0, (hipStream_t)stream,
                                             (const T*)x, scale, shift, (const T*)r, scale2, shift2, (T*)y, HW, C, units,
                                             s1_per_n, relu & 1));
   AST_CHECK_LAUNCH();
@@ -468,7 +504,8 @@ extern "C" int ast_norm_bwd_apply_pre(const void* dy, const void* y, const void*
   if (!dy || (relu && !y && !scale1) || (dx && k1 && !x) || (dr && (!r || !k2)) || (C & 7)) AST_FAIL("ast_norm_bwd_apply: bad args");
   if (scale1 && (!x || !shift1 || (r && (!scale2 || !shift2)))) AST_FAIL("ast_norm_bwd_apply: incomplete pre-activation coefficients");
   const size_t units = (size_t)N * HW * (C >> 3);
-  AST_DISPATCH_T(dtype, hipLaunchKernelGGL((norm_bwd_apply_kernel<T>), dim3(grid_for(units)), dim3(256), 0,
+  const dim3 bgrid(std::max(1, std::min<int>((int)(((size_t)HW * (C >> 3) + 255) / 256), std::max(1, 4096 / N))), N);
+  AST_DISPATCH_T(dtype, hipLaunchKernelGGL((norm_bwd_apply_kernel<T>), bgrid, dim3(256), 0,
                                             (hipStream_t)stream, (const T*)dy, (const T*)y, (const T*)x, (const T*)r, k1, k2,
                                             (T*)dx, (T*)dr, HW, C, units, relu, scale1, shift1, scale2, shift2));
   AST_CHECK_LAUNCH();
