@@ -421,6 +421,8 @@ __global__ void add_drop_ln_bwd_kernel(const float* __restrict__ dy, const float
 // point where the chip runs dry (A/B on the whole step: 8192 -> 8.9 ms, 4096 -> 8.35, 2048 -> 7.9, 1024 -> 7.5, 256 -> 7.55)
 int reduce_blocks() { static const int v = getenv("AST_REDUCE_BLOCKS") ? atoi(getenv("AST_REDUCE_BLOCKS")) : 1024; return v; }
 
+int elem_blocks() { static const int v = getenv("AST_ELEM_BLOCKS") ? atoi(getenv("AST_ELEM_BLOCKS")) : 2048; return v; }
+
 int grid_for(size_t n, int block = 256) { return (int)std::min<size_t>((n + block - 1) / block, 256 * 16); }
 
 }  // namespace
@@ -460,7 +462,7 @@ extern "C" int ast_affine_act(const void* x, const float* scale, const float* sh
   const size_t units = (size_t)N * HW * (C >> 3);
   // scale given per channel ([C]); the instance form ([N][C]) is requested with relu bit 2
   const int s1_per_n = (relu >> 1) & 1;
-  const dim3 agrid(std::max(1, std::min<int>((int)(((size_t)HW * (C >> 3) + 255) / 256), std::max(1, 4096 / N))), N);
+  const dim3 agrid(std::max(1, std::min<int>((int)(((size_t)HW * (C >> 3) + 255) / 256), std::max(1, elem_blocks() / N))), N);
   AST_DISPATCH_T(dtype, hipLaunchKernelGGL((affine_act_kernel<T>), agrid, dim3(256), 0, (hipStream_t)stream,
                                             (const T*)x, scale, shift, (const T*)r, scale2, shift2, (T*)y, HW, C, units,
                                             s1_per_n, relu & 1));
@@ -508,7 +510,7 @@ extern "C" int ast_norm_bwd_apply_pre(const void* dy, const void* y, const void*
   if (!dy || (relu && !y && !scale1) || (dx && k1 && !x) || (dr && (!r || !k2)) || (C & 7)) AST_FAIL("ast_norm_bwd_apply: bad args");
   if (scale1 && (!x || !shift1 || (r && (!scale2 || !shift2)))) AST_FAIL("ast_norm_bwd_apply: incomplete pre-activation coefficients");
   const size_t units = (size_t)N * HW * (C >> 3);
-  const dim3 bgrid(std::max(1, std::min<int>((int)(((size_t)HW * (C >> 3) + 255) / 256), std::max(1, 4096 / N))), N);
+  const dim3 bgrid(std::max(1, std::min<int>((int)(((size_t)HW * (C >> 3) + 255) / 256), std::max(1, elem_blocks() / N))), N);
   AST_DISPATCH_T(dtype, hipLaunchKernelGGL((norm_bwd_apply_kernel<T>), bgrid, dim3(256), 0,
                                             (hipStream_t)stream, (const T*)dy, (const T*)y, (const T*)x, (const T*)r, k1, k2,
                                             (T*)dx, (T*)dr, HW, C, units, relu, scale1, shift1, scale2, shift2));
