@@ -417,6 +417,99 @@ __global__ void add_drop_ln_bwd_kernel(const float* __restrict__ dy, const float
   }
 }
 
+// D == 256 forms: a lane owns 4 consecutive elements, every operand is one 16-byte load issued up front (one memory
+// round trip instead of three or four dependent ones), and the gamma/beta gradients of the workgroup's 4 rows are
+// summed in LDS before ONE pair of atomics per element (an atomic costs its issue slot).
+__global__ __launch_bounds__(256) void add_drop_ln_fwd256_kernel(const float* __restrict__ x, const float* __restrict__ sub,
+                                                                 float* __restrict__ mask, float* __restrict__ s_out,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                                 int rows, float eps, float p, uint64_t seed,
+                                                                 const int64_t* __restrict__ d_offset) {
+  constexpr int D = 256;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const size_t o = (size_t)row * D + lane * 4;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 sv = *reinterpret_cast<const f32x4*>(sub + o);
+  const f32x4 xv = x ? *reinterpret_cast<const f32x4*>(x + o) : z;
+  const f32x4 g4 = gamma ? *reinterpret_cast<const f32x4*>(gamma + lane * 4) : z;
+  const f32x4 b4 = gamma ? *reinterpret_cast<const f32x4*>(beta + lane * 4) : z;
+  const uint64_t base = p > 0.f ? mix64(seed ^ mix64((uint64_t)(d_offset ? *d_offset : 0))) : 0;
+  __builtin_amdgcn_sched_barrier(0);
+  const float keep = 1.f / (1.f - p);
+  f32x4 sv2 = sv;
+  if (p > 0.f) {
+    f32x4 m4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { m4[e] = dropout_keep(base, o + e, p, keep); sv2[e] *= m4[e]; }
+    *reinterpret_cast<f32x4*>(mask + o) = m4;
+  }
+  f32x4 s4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s4[e] = x ? sv2[e] + xv[e] : sv2[e];
+  *reinterpret_cast<f32x4*>(s_out + o) = s4;
+  if (!gamma) return;
+  const float m = wave_sum(s4[0] + s4[1] + s4[2] + s4[3]) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const float d = s4[e] - m; q += d * d; }
+  const float r = rsqrtf(wave_sum(q) / D + eps);
+  f32x4 y4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) y4[e] = (s4[e] - m) * r * g4[e] + b4[e];
+  *reinterpret_cast<f32x4*>(y + o) = y4;
+  if (lane == 0) { mean[row] = m; rstd[row] = r; }
+}
+
+__global__ __launch_bounds__(256) void add_drop_ln_bwd256_kernel(const float* __restrict__ dy, const float* __restrict__ ds_ext,
+                                                                 const float* __restrict__ s, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ mask, float* __restrict__ dx,
+                                                                 float* __restrict__ dsub, float* dgamma, float* dbeta, int rows) {
+  constexpr int D = 256;
+  __shared__ float red[2][4][D];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  const bool valid = row < rows;
+  const size_t o = (size_t)(valid ? row : 0) * D + lane * 4;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 dy4 = dy ? *reinterpret_cast<const f32x4*>(dy + o) : z;
+  const f32x4 s4 = dy ? *reinterpret_cast<const f32x4*>(s + o) : z;
+  const f32x4 g4 = dy ? *reinterpret_cast<const f32x4*>(gamma + lane * 4) : z;
+  const f32x4 e4 = ds_ext ? *reinterpret_cast<const f32x4*>(ds_ext + o) : z;
+  const f32x4 k4 = mask ? *reinterpret_cast<const f32x4*>(mask + o) : f32x4{1.f, 1.f, 1.f, 1.f};
+  const float m = dy ? mean[valid ? row : 0] : 0.f, r = dy ? rstd[valid ? row : 0] : 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 d4 = e4, xh4 = z;
+  if (dy) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { xh4[e] = (s4[e] - m) * r; const float g = dy4[e] * g4[e]; a += g; b += g * xh4[e]; }
+    a = wave_sum(a) / D; b = wave_sum(b) / D;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d4[e] += r * (dy4[e] * g4[e] - a - xh4[e] * b);
+  }
+  if (valid) {
+    if (dx) *reinterpret_cast<f32x4*>(dx + o) = d4;
+    f32x4 ds4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ds4[e] = d4[e] * k4[e];
+    *reinterpret_cast<f32x4*>(dsub + o) = ds4;
+  }
+  if (dy && (dgamma || dbeta)) {              // uniform per launch: every wave reaches the barrier
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][wave][lane * 4 + e] = valid ? dy4[e] * xh4[e] : 0.f;
+      red[1][wave][lane * 4 + e] = valid ? dy4[e] : 0.f;
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (dgamma) unsafeAtomicAdd(dgamma + i, red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i]);
+    if (dbeta) unsafeAtomicAdd(dbeta + i, red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
+  }
+}
+
 // workgroups per statistics pass: every workgroup ends with C*K same-address f32 atomics, so FEWER is faster up to the
 // point where the chip runs dry (A/B on the whole step: 8192 -> 8.9 ms, 4096 -> 8.35, 2048 -> 7.9, 1024 -> 7.5, 256 -> 7.55)
 int reduce_blocks() { static const int v = getenv("AST_REDUCE_BLOCKS") ? atoi(getenv("AST_REDUCE_BLOCKS")) : 1024; return v; }
@@ -550,8 +643,14 @@ extern "C" int ast_add_drop_ln_fwd(const float* x, const float* sub, float* mask
   if (!sub || !s_out || rows <= 0 || D <= 0 || p < 0.f || p >= 1.f) AST_FAIL("ast_add_drop_ln_fwd: bad args");
   if (p > 0.f && !mask) AST_FAIL("ast_add_drop_ln_fwd: dropout needs a mask buffer");
   if (gamma && (!beta || !y || !mean || !rstd)) AST_FAIL("ast_add_drop_ln_fwd: LayerNorm outputs missing");
-  hipLaunchKernelGGL(add_drop_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, sub, mask, s_out, gamma, beta,
-                     y, mean, rstd, rows, D, eps, p, seed, d_offset);
+  const bool al = ((((uintptr_t)x) | ((uintptr_t)sub) | ((uintptr_t)mask) | ((uintptr_t)s_out) | ((uintptr_t)gamma) | ((uintptr_t)beta) |
+                    ((uintptr_t)y)) & 15) == 0;
+  if (D == 256 && al)
+    hipLaunchKernelGGL(add_drop_ln_fwd256_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, sub, mask, s_out, gamma,
+                       beta, y, mean, rstd, rows, eps, p, seed, d_offset);
+  else
+    hipLaunchKernelGGL(add_drop_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, sub, mask, s_out, gamma, beta,
+                       y, mean, rstd, rows, D, eps, p, seed, d_offset);
   AST_CHECK_LAUNCH();
   return 0;
 }
@@ -561,8 +660,14 @@ extern "C" int ast_add_drop_ln_bwd(const float* dy, const float* ds_ext, const f
                                    int D, void* stream) {
   if ((!dy && !ds_ext) || !dsub || rows <= 0 || D <= 0) AST_FAIL("ast_add_drop_ln_bwd: bad args");
   if (dy && (!s || !gamma || !mean || !rstd)) AST_FAIL("ast_add_drop_ln_bwd: LayerNorm state missing");
-  hipLaunchKernelGGL(add_drop_ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, ds_ext, s, gamma, mean, rstd,
-                     mask, dx, dsub, dgamma, dbeta, rows, D);
+  const bool al = ((((uintptr_t)dy) | ((uintptr_t)ds_ext) | ((uintptr_t)s) | ((uintptr_t)gamma) | ((uintptr_t)mask) | ((uintptr_t)dx) |
+                    ((uintptr_t)dsub)) & 15) == 0;
+  if (D == 256 && al)
+    hipLaunchKernelGGL(add_drop_ln_bwd256_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, ds_ext, s, gamma, mean, rstd,
+                       mask, dx, dsub, dgamma, dbeta, rows);
+  else
+    hipLaunchKernelGGL(add_drop_ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, ds_ext, s, gamma, mean, rstd,
+                       mask, dx, dsub, dgamma, dbeta, rows, D);
   AST_CHECK_LAUNCH();
   return 0;
 }
