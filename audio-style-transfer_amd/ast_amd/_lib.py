@@ -76,6 +76,8 @@ _SIGS = {
     "ast_attn_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp], i32),
     "ast_attn_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp], i32),
     "ast_rowmix": ([vp, vp, vp, i32, i32, i32, vp], i32),
+    "ast_attn_fwd_p": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, f32, C.c_uint64, vp, vp], i32),
+    "ast_attn_bwd_p": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, f32, C.c_uint64, vp, vp], i32),
     "ast_add": ([vp, vp, vp, i64, i32, vp], i32),
     "ast_relu_bwd": ([vp, vp, vp, i64, i32, vp], i32),
     "ast_dropout_mask": ([vp, i64, f32, C.c_uint64, vp, vp], i32),

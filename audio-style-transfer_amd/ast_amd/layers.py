@@ -278,8 +278,7 @@ class MHA:
             Lk = Lq
             q = kv = linear(x.reshape(B * Lq, d), self.qkv)
             k_off, v_off = d, 2 * d
-        mask = ops.dropout_mask((B, self.h, Lq, Lk), p_drop, x.device) if (training and p_drop > 0) else None
-        o = ops.AttnCoreFn.apply(q, kv, B, self.h, Lq, Lk, dh, k_off, v_off, causal, mask)
+        o = ops.AttnCoreFn.apply(q, kv, B, self.h, Lq, Lk, dh, k_off, v_off, causal, float(p_drop) if training else 0.0)
         return linear(o, self.out).view(B, Lq, d)
 
 

@@ -916,32 +916,41 @@ class CastFn(torch.autograd.Function):
 # attention core + dropout
 # ---------------------------------------------------------------------------
 class AttnCoreFn(torch.autograd.Function):
-    """softmax(QK^T/sqrt(dh) + causal) V for <=16 tokens.  q:(B*Lq, ldq) k,v views of (B*Lk, ldk)."""
+    """softmax(QK^T/sqrt(dh) + causal) V for <=16 tokens.  q:(B*Lq, ldq) k,v views of (B*Lk, ldk).
+    p_drop > 0: the attention-probability dropout is drawn inside the kernels (same values forward and backward)."""
 
     @staticmethod
-    def forward(ctx, q, kv, B, H, Lq, Lk, dh, k_off, v_off, causal, drop_mask):
+    def forward(ctx, q, kv, B, H, Lq, Lk, dh, k_off, v_off, causal, p_drop):
         d = H * dh
         o = torch.empty((B * Lq, d), dtype=torch.float32, device=q.device)
         probs = torch.empty((B, H, Lq, Lk), dtype=torch.float32, device=q.device)
         ldq, ldk = q.stride(0), kv.stride(0)
-        check(lib().ast_attn_fwd(q.data_ptr(), kv.data_ptr() + 4 * k_off, kv.data_ptr() + 4 * v_off, ptr(o), ptr(probs),
-                                 B, H, Lq, Lk, dh, ldq, ldk, d, int(causal), ptr(drop_mask), stream()), "ast_attn_fwd")
-        ctx.save_for_backward(q, kv, probs, drop_mask)
+        seed, ctr = 0, None
+        if p_drop > 0.0:
+            if _DropState.counter is None or _DropState.counter.device != q.device:
+                _DropState.counter = torch.zeros(1, dtype=torch.int64, device=q.device)
+            _DropState.calls += 1
+            seed, ctr = _DropState.seed + 7919 * _DropState.calls, _DropState.counter
+        check(lib().ast_attn_fwd_p(q.data_ptr(), kv.data_ptr() + 4 * k_off, kv.data_ptr() + 4 * v_off, ptr(o), ptr(probs),
+                                   B, H, Lq, Lk, dh, ldq, ldk, d, int(causal), None, float(p_drop), seed, ptr(ctr), stream()), "ast_attn_fwd")
+        ctx.save_for_backward(q, kv, probs)
         ctx.dims = (B, H, Lq, Lk, dh, k_off, v_off)
+        ctx.drop = (float(p_drop), seed, ctr)
         ctx.same = q.data_ptr() == kv.data_ptr()
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, kv, probs, drop_mask = ctx.saved_tensors
+        q, kv, probs = ctx.saved_tensors
         B, H, Lq, Lk, dh, k_off, v_off = ctx.dims
+        p_drop, seed, ctr = ctx.drop
         do = do.contiguous()
         d = H * dh
         dq = torch.empty_like(q)                    # the kernel writes every q / k / v column of every row
         dkv = dq if ctx.same else torch.empty_like(kv)
-        check(lib().ast_attn_bwd(ptr(do), q.data_ptr(), kv.data_ptr() + 4 * k_off, kv.data_ptr() + 4 * v_off, ptr(probs),
-                                 dq.data_ptr(), dkv.data_ptr() + 4 * k_off, dkv.data_ptr() + 4 * v_off, B, H, Lq, Lk, dh,
-                                 q.stride(0), kv.stride(0), d, ptr(drop_mask), stream()), "ast_attn_bwd")
+        check(lib().ast_attn_bwd_p(ptr(do), q.data_ptr(), kv.data_ptr() + 4 * k_off, kv.data_ptr() + 4 * v_off, ptr(probs),
+                                   dq.data_ptr(), dkv.data_ptr() + 4 * k_off, dkv.data_ptr() + 4 * v_off, B, H, Lq, Lk, dh,
+                                   q.stride(0), kv.stride(0), d, None, p_drop, seed, ptr(ctr), stream()), "ast_attn_bwd")
         return dq, (None if ctx.same else dkv), None, None, None, None, None, None, None, None, None
 
 

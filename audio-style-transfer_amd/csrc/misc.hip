@@ -169,7 +169,13 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, T* __restrict_
 constexpr int MAXL = 16;
 __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                        float* __restrict__ o, float* __restrict__ probs, int H, int Lq, int Lk, int dh,
-                                                       int ldq, int ldk, int ldo, int causal, const float* __restrict__ drop) {
+                                                       int ldq, int ldk, int ldo, int causal, const float* __restrict__ drop,
+                                                       float pdrop, uint64_t seed, const int64_t* __restrict__ d_offset) {
+  // attention-probability dropout: either a precomputed mask (`drop`) or, with pdrop > 0, the mask value is DRAWN here
+  // from (seed, step counter, element index) -- the backward kernel draws the same values again, so no mask tensor
+  // and no mask kernel exist
+  const uint64_t dbase = pdrop > 0.f ? mix64(seed ^ mix64((uint64_t)(d_offset ? *d_offset : 0))) : 0;
+  const float dkeep = 1.f / (1.f - pdrop);
   const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
   const float scale = rsqrtf((float)dh);
   float kv[MAXL], vv[MAXL];
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
     for (int j = 0; j < Lk; ++j) {
       const float p = s[j] / den;
       if (lane == 0) probs[pbase + j] = p;
-      acc += (drop ? p * drop[pbase + j] : p) * vv[j];
+      acc += (drop ? p * drop[pbase + j] : (pdrop > 0.f ? p * dropout_keep(dbase, pbase + j, pdrop, dkeep) : p)) * vv[j];
     }
     if (lane < dh) o[((size_t)b * Lq + i) * ldo + h * dh + lane] = acc;
   }
@@ -202,7 +208,10 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, const float* __restrict__ probs, float* __restrict__ dq,
                                                        float* __restrict__ dk, float* __restrict__ dv, int H, int Lq, int Lk, int dh, int ldq,
-                                                       int ldk, int ldo, const float* __restrict__ drop) {
+                                                       int ldk, int ldo, const float* __restrict__ drop, float pdrop, uint64_t seed,
+                                                       const int64_t* __restrict__ d_offset) {
+  const uint64_t dbase = pdrop > 0.f ? mix64(seed ^ mix64((uint64_t)(d_offset ? *d_offset : 0))) : 0;
+  const float dkeep = 1.f / (1.f - pdrop);
   const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
   const float scale = rsqrtf((float)dh);
   float kv[MAXL], vv[MAXL], dkv[MAXL], dvv[MAXL];
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
     float dot = 0.f;
     for (int j = 0; j < Lk; ++j) {
       p[j] = probs[pbase + j];
-      const float m = drop ? drop[pbase + j] : 1.f;
+      const float m = drop ? drop[pbase + j] : (pdrop > 0.f ? dropout_keep(dbase, pbase + j, pdrop, dkeep) : 1.f);
       dvv[j] += p[j] * m * doi;
       dp[j] = wave_sum(doi * vv[j]) * m;
       dot += dp[j] * p[j];
@@ -392,24 +401,34 @@ extern "C" int ast_bilinear_bwd(const float* dy, void* dx, int N, int C, int Cp,
   return 0;
 }
 
-extern "C" int ast_attn_fwd(const float* q, const float* k, const float* v, float* o, float* probs, int B, int H, int Lq, int Lk,
-                            int dh, int ldq, int ldk, int ldo, int causal, const float* drop_mask, void* stream) {
-  if (!q || !k || !v || !o || !probs) AST_FAIL("ast_attn_fwd: null pointer");
+extern "C" int ast_attn_fwd_p(const float* q, const float* k, const float* v, float* o, float* probs, int B, int H, int Lq, int Lk,
+                              int dh, int ldq, int ldk, int ldo, int causal, const float* drop_mask, float p, uint64_t seed,
+                              const int64_t* d_offset, void* stream) {
+  if (!q || !k || !v || !o || !probs || p < 0.f || p >= 1.f) AST_FAIL("ast_attn_fwd: bad args");
   if (Lq < 1 || Lk < 1 || Lq > MAXL || Lk > MAXL || dh < 1 || dh > 64) AST_FAIL("ast_attn_fwd: needs 1<=L<=%d and dh<=64 (Lq=%d Lk=%d dh=%d)", MAXL, Lq, Lk, dh);
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, q, k, v, o, probs, H, Lq, Lk, dh, ldq, ldk, ldo,
-                     causal, drop_mask);
+                     causal, drop_mask, p, seed, d_offset);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int ast_attn_fwd(const float* q, const float* k, const float* v, float* o, float* probs, int B, int H, int Lq, int Lk,
+                            int dh, int ldq, int ldk, int ldo, int causal, const float* drop_mask, void* stream) {
+  return ast_attn_fwd_p(q, k, v, o, probs, B, H, Lq, Lk, dh, ldq, ldk, ldo, causal, drop_mask, 0.f, 0, nullptr, stream);
+}
+extern "C" int ast_attn_bwd_p(const float* dout, const float* q, const float* k, const float* v, const float* probs, float* dq, float* dk,
+                              float* dv, int B, int H, int Lq, int Lk, int dh, int ldq, int ldk, int ldo, const float* drop_mask,
+                              float p, uint64_t seed, const int64_t* d_offset, void* stream) {
+  if (!dout || !q || !k || !v || !probs || !dq || !dk || !dv || p < 0.f || p >= 1.f) AST_FAIL("ast_attn_bwd: bad args");
+  if (Lq < 1 || Lk < 1 || Lq > MAXL || Lk > MAXL || dh < 1 || dh > 64) AST_FAIL("ast_attn_bwd: needs 1<=L<=%d and dh<=64", MAXL);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, dout, q, k, v, probs, dq, dk, dv, H, Lq, Lk, dh,
+                     ldq, ldk, ldo, drop_mask, p, seed, d_offset);
   AST_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int ast_attn_bwd(const float* dout, const float* q, const float* k, const float* v, const float* probs, float* dq, float* dk,
                             float* dv, int B, int H, int Lq, int Lk, int dh, int ldq, int ldk, int ldo, const float* drop_mask,
                             void* stream) {
-  if (!dout || !q || !k || !v || !probs || !dq || !dk || !dv) AST_FAIL("ast_attn_bwd: null pointer");
-  if (Lq < 1 || Lk < 1 || Lq > MAXL || Lk > MAXL || dh < 1 || dh > 64) AST_FAIL("ast_attn_bwd: needs 1<=L<=%d and dh<=64", MAXL);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, dout, q, k, v, probs, dq, dk, dv, H, Lq, Lk, dh,
-                     ldq, ldk, ldo, drop_mask);
-  AST_CHECK_LAUNCH();
-  return 0;
+  return ast_attn_bwd_p(dout, q, k, v, probs, dq, dk, dv, B, H, Lq, Lk, dh, ldq, ldk, ldo, drop_mask, 0.f, 0, nullptr, stream);
 }
 
 extern "C" int ast_add(const void* a, const void* b, void* y, int64_t n, int dtype, void* stream) {

@@ -225,6 +225,15 @@ int ast_attn_fwd(const float* q, const float* k, const float* v, float* o, float
 int ast_attn_bwd(const float* dout, const float* q, const float* k, const float* v, const float* probs,
                  float* dq, float* dk, float* dv, int B, int H, int Lq, int Lk, int dh, int ldq,
                  int ldk, int ldo, const float* drop_mask, void* stream);
+/* The same with the attention-probability dropout DRAWN in the kernel (p, seed, d_offset as ast_dropout_fwd; element
+ * index = ((b*H + h)*Lq + i)*Lk + j): forward and backward draw identical values, so no mask tensor is stored and no
+ * mask kernel runs (nn.MultiheadAttention(dropout=0.1), style_encoder.py:181-187, new_decoder.py:111-118). */
+int ast_attn_fwd_p(const float* q, const float* k, const float* v, float* o, float* probs, int B, int H, int Lq, int Lk,
+                   int dh, int ldq, int ldk, int ldo, int causal, const float* drop_mask, float p, uint64_t seed,
+                   const int64_t* d_offset, void* stream);
+int ast_attn_bwd_p(const float* dout, const float* q, const float* k, const float* v, const float* probs, float* dq, float* dk,
+                   float* dv, int B, int H, int Lq, int Lk, int dh, int ldq, int ldk, int ldo, const float* drop_mask,
+                   float p, uint64_t seed, const int64_t* d_offset, void* stream);
 
 /* ---- elementwise ------------------------------------------------------------- */
 /* out[c] += sum_r x[r][c], c < Creal  (bias gradients of Conv2d / Linear) */

@@ -279,6 +279,31 @@ def test_layernorm():
     assert rel_err(xh.grad, xr.grad) < 1e-4 and rel_err(ln.weight.grad, wr.grad) < 1e-4 and rel_err(ln.bias.grad, br.grad) < 1e-4
 
 
+def test_attention_dropout_drawn_in_kernel():
+    """ast_attn_fwd_p / ast_attn_bwd_p: the attention-probability dropout mask is never materialised; forward and
+    backward draw it from (seed, counter, element index).  Checked against torch with the mask rebuilt on the host."""
+    torch.manual_seed(31)
+    B, H, Lq, Lk, dh = 3, 4, 3, 5, 64
+    d = H * dh
+    q = torch.randn(B * Lq, d)
+    kv = torch.randn(B * Lk, 2 * d)
+    ops._DropState.calls = 2000
+    qh, kvh = q.to(DEV).requires_grad_(True), kv.to(DEV).requires_grad_(True)
+    o = ops.AttnCoreFn.apply(qh, kvh, B, H, Lq, Lk, dh, 0, d, False, 0.3)
+    mask = host_dropout_mask(ops._DropState.seed + 7919 * 2001, int(ops._DropState.counter.item()), B * H * Lq * Lk, 0.3).view(B, H, Lq, Lk)
+    qr, kvr = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    Q = qr.view(B, Lq, H, dh).transpose(1, 2)
+    K = kvr[:, :d].reshape(B, Lk, H, dh).transpose(1, 2)
+    V = kvr[:, d:].reshape(B, Lk, H, dh).transpose(1, 2)
+    P = torch.softmax(Q @ K.transpose(-1, -2) / math.sqrt(dh), dim=-1) * mask
+    oref = (P @ V).transpose(1, 2).reshape(B * Lq, d)
+    g = torch.randn_like(oref)
+    oref.backward(g)
+    assert rel_err(o, oref) < 1e-4
+    o.backward(g.to(DEV))
+    assert rel_err(qh.grad, qr.grad) < 1e-4 and rel_err(kvh.grad, kvr.grad) < 1e-4
+
+
 @pytest.mark.parametrize("rows", [4, 20])
 def test_big_linears_of_simple_decoder(rows):
     """ast_bigk_gemm / ast_skinny_gemm(N huge) / ast_bign_dgrad / ast_linear_wgrad on the 2*287*513 x 256 linears of
