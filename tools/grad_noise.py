@@ -19,9 +19,12 @@ for it in range(6):
     res = []
     for tag in ("style", "content", "decoder"):
         num = den = 0.0
+        worst = 0.0
         for k, p in ms[tag].named_parameters():
             ref = o["sds"][tag][k].grad
             if ref is None or p.grad is None: continue
             num += float((p.grad.double().cpu() - ref.double()).pow(2).sum()); den += float(ref.double().pow(2).sum())
-        res.append(f"{tag} {math.sqrt(num / den):.2e}")
+            if float(ref.norm()) >= 1e-3:
+                worst = max(worst, T.rel_l2(p.grad, ref))
+        res.append(f"{tag} {math.sqrt(num / den):.2e} (worst parameter {worst:.1e})")
     print(it, " ".join(res), flush=True)
