@@ -17,6 +17,12 @@ x = torch.randn(N, H, W, Cs, device="cuda").to(dt); w = torch.randn(Cd, k * k, C
 y = torch.empty(N, Ho, Wo, Cd, device="cuda", dtype=dt)
 ws = torch.zeros(max(1, N * Ho * Wo * Cd), device="cuda")
 torch.cuda.synchronize()
-for _ in range(iters):
-    check(lib().ast_igemm(ptr(x), ptr(w), None, ptr(y), g, dcode(dt), 4, ptr(ws), ws.numel(), stream()))
+if len(sys.argv) > 3 and sys.argv[3] == "wgrad":          # the weight gradient of the same layer: dW[Cd][taps][Cs] += dy^T . gather(x)
+    dy = torch.randn(N, Ho, Wo, Cd, device="cuda").to(dt)
+    dw = torch.zeros(Cd, k * k, Cs, device="cuda")
+    for _ in range(iters):
+        check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(dw), g, dcode(dt), stream()))
+else:
+    for _ in range(iters):
+        check(lib().ast_igemm(ptr(x), ptr(w), None, ptr(y), g, dcode(dt), 4, ptr(ws), ws.numel(), stream()))
 torch.cuda.synchronize()

@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"; do
+  tag=$(echo $set | cut -c1-12 | tr ' ' '_')
+  timeout -k 5 90 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_wg_$tag -- python3 tools/one_layer.py $1 3 wgrad > gpurun_out/pmc_wg_$tag.log 2>&1 || exit 1
+done
