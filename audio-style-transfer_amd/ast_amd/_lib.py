@@ -50,6 +50,7 @@ _SIGS = {
     "ast_bign_dgrad": ([vp, vp, vp, i32, i32, i32, i32, vp], i32),
     "ast_linear_wgrad": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "ast_linear_wgrad_batched": ([vp, i32, i32, vp], i32),
+    "ast_linear_wgrad_batched_host": ([vp, i32, i32, vp], i32),
     "ast_nchw_to_nhwc": ([vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, i32, vp], i32),
     "ast_nhwc_to_nchw": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "ast_cast": ([vp, i32, vp, i32, i64, vp], i32),

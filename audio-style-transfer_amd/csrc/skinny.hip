@@ -267,8 +267,22 @@ __global__ __launch_bounds__(256) void bign_dgrad_kernel(const float* __restrict
 // table[e] = {dy, x, dW, db, M, N, K, lddy, ldw}; blockIdx.y = entry, blockIdx.x = (k tile, n tile-of-64) of that entry.
 struct LinWg { const float* dy; const float* x; float* dW; float* db; int M, N, K, lddy, ldw, pad0, pad1, pad2; };
 
+// The records travel as a by-value kernel argument (<= 56 x 64 B, under the 4 KB kernarg limit): no device table, no
+// host-to-device copy node in the captured step (each such memcpy node cost a 20-75 us bubble in the replay).
+constexpr int LINWG_MAX = 56;
+struct LinWgArgs { LinWg rec[LINWG_MAX]; };
+
+__device__ __forceinline__ void linear_wgrad_entry(const LinWg& e);
+
+__global__ __launch_bounds__(256) void linear_wgrad_batched_args_kernel(const LinWgArgs tab) {
+  linear_wgrad_entry(tab.rec[blockIdx.y]);         // uniform index: scalar loads from the kernarg segment
+}
+
 __global__ __launch_bounds__(256) void linear_wgrad_batched_kernel(const LinWg* __restrict__ table) {
-  const LinWg e = table[blockIdx.y];
+  linear_wgrad_entry(table[blockIdx.y]);
+}
+
+__device__ __forceinline__ void linear_wgrad_entry(const LinWg& e) {
   const int ktiles = (e.K + 63) / 64, ntiles = (e.N + 63) / 64;
   if ((int)blockIdx.x >= ktiles * ntiles) return;
   const int kt = blockIdx.x % ktiles, nt = blockIdx.x / ktiles;
@@ -337,6 +351,20 @@ __global__ __launch_bounds__(256) void linear_wgrad_batched_kernel(const LinWg* 
   }
 }
 }  // namespace
+
+extern "C" int ast_linear_wgrad_batched_host(const void* host_table, int count, int max_tiles, void* stream) {
+  if (!host_table || count <= 0 || max_tiles <= 0) AST_FAIL("ast_linear_wgrad_batched_host: bad args");
+  const LinWg* recs = (const LinWg*)host_table;
+  for (int c0 = 0; c0 < count; c0 += LINWG_MAX) {
+    const int n = std::min(LINWG_MAX, count - c0);
+    LinWgArgs args;
+    memset(&args, 0, sizeof(args));
+    memcpy(args.rec, recs + c0, sizeof(LinWg) * n);
+    hipLaunchKernelGGL(linear_wgrad_batched_args_kernel, dim3(max_tiles, n), dim3(256), 0, (hipStream_t)stream, args);
+  }
+  AST_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int ast_linear_wgrad_batched(const void* table, int count, int max_tiles, void* stream) {
   if (!table || count <= 0 || max_tiles <= 0) AST_FAIL("ast_linear_wgrad_batched: bad args");

@@ -99,6 +99,9 @@ int ast_linear_wgrad(const float* dy, const float* x, float* dW, float* db, int 
  * {const float* dy, x; float* dW, db; int32 M, N, K, lddy, ldw, pad[3]} (64 bytes each); max_tiles >= max over
  * records of ceil(K/64)*ceil(N/64).  One launch for every linear layer of a model, after backward. */
 int ast_linear_wgrad_batched(const void* table, int count, int max_tiles, void* stream);
+/* The same with the records read from HOST memory at call time and passed to the kernel by value (<= 56 per launch):
+ * no device table and no host-to-device copy, so the call is a plain kernel node under hipGraph capture. */
+int ast_linear_wgrad_batched_host(const void* host_table, int count, int max_tiles, void* stream);
 
 /* ---- layout conversion at the module boundary ------------------------------ */
 /* x (N,C,H,W) f32, element (n,c,h,w) at n*sn + c*sc + h*sh + w  ->  NHWC dtype, Cp>=C zero padded.
