@@ -65,6 +65,8 @@ _SIGS = {
     "ast_norm_bwd_sums_pre": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp], i32),
     "ast_norm_bwd_apply_pre": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp], i32),
     "ast_norm_bwd_finalize": ([vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i32),
+    "ast_norm_bwd_finalize_n": ([vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_long, vp], i32),
+    "ast_igemm_bn": ([vp, vp, vp, vp, C.POINTER(Gather), i32, i32, vp, C.c_long, vp, vp, vp, vp], i32),
     "ast_norm_bwd_apply": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "ast_layernorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp], i32),
     "ast_layernorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),

@@ -26,3 +26,7 @@ fused_bn_stats = _os.environ.get("AST_FUSED_BN_STATS", "1") != "0"
 # BatchNorm/ResBlock-tail backward: recompute the ReLU mask from the pre-activation (x, scale, shift) instead of
 # reading the activation output (AST_BN_MASK_FROM_PREACT=0 reads y: the reference path for A/B timing).
 bn_mask_from_preact = _os.environ.get("AST_BN_MASK_FROM_PREACT", "1") != "0"
+
+# BatchNorm backward sums accumulated in the epilogue of the data-gradient GEMM that produces the layer's dy
+# (AST_FUSED_BN_BWD=0 keeps the separate pass over dy and x).
+fused_bn_bwd = _os.environ.get("AST_FUSED_BN_BWD", "1") != "0"

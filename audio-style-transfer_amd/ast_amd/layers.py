@@ -175,12 +175,25 @@ def tok_dtype():
 
 
 # ---- thin functional wrappers --------------------------------------------------------
+def _link_of(x):
+    """BNLink left on a BatchNorm(+ReLU) output by bn_act / conv_bn_act / convT_bn_act (None otherwise)."""
+    return getattr(x, "_bn_link", None)
+
+
 def conv(x, pw, k, stride, pad, bias_grad):
-    return ops.Conv2dFn.apply(x, pw.weight, pw, k, stride, pad, bias_grad)
+    return ops.Conv2dFn.apply(x, pw.weight, pw, k, stride, pad, bias_grad, None, _link_of(x))
 
 
 def convT(x, pw, k, stride, pad, out_pad, bias_grad):
-    return ops.ConvT2dFn.apply(x, pw.weight, pw, k, stride, pad, out_pad, bias_grad)
+    return ops.ConvT2dFn.apply(x, pw.weight, pw, k, stride, pad, out_pad, bias_grad, None, _link_of(x))
+
+
+def _bn_apply(y, bn, training, relu, stats):
+    link = ops.BNLink() if (training and config.fused_bn_bwd) else None
+    out = ops.BatchNormActFn.apply(y, bn.weight, bn.bias, bn, training, relu, stats, link)
+    if link is not None:
+        out._bn_link = link              # read by the conv that consumes `out` (conv / convT / conv_with_stats)
+    return out
 
 
 def linear(x2d, pw, relu=False):
@@ -188,8 +201,8 @@ def linear(x2d, pw, relu=False):
     return y if pw.Cop == pw.Co else y[:, :pw.Co]
 
 
-def bn_act(x, bn: nn.BatchNorm2d, training, relu=True):
-    return ops.BatchNormActFn.apply(x, bn.weight, bn.bias, bn, training, relu)
+def bn_act(x, bn: nn.BatchNorm2d, training, relu=True, stats=None):
+    return _bn_apply(x, bn, training, relu, stats)
 
 
 def conv_with_stats(x, pw, k, stride, pad, training):
@@ -202,7 +215,7 @@ def conv_with_stats(x, pw, k, stride, pad, training):
         g, _ = ops.gather_direct(N, H, W, Cs, pw.Cop, k, stride, pad)
         if ops.stats_fusable(g, ops.dcode(x.dtype)):
             stats = ops._clean_scratch(ops.STAT_SLOTS * pw.Cop * 2, x.device, tag="bn-stats")
-    return ops.Conv2dFn.apply(x, pw.weight, pw, k, stride, pad, False, stats), stats
+    return ops.Conv2dFn.apply(x, pw.weight, pw, k, stride, pad, False, stats, _link_of(x)), stats
 
 
 def convT_bn_act(x, pw, k, stride, pad, out_pad, bn: nn.BatchNorm2d, training, relu=True):
@@ -215,8 +228,8 @@ def convT_bn_act(x, pw, k, stride, pad, out_pad, bn: nn.BatchNorm2d, training, r
         gs = ops.gathers_transposed(N, H, W, Cs, Ho, Wo, pw.Cop, k, stride, pad)
         if all(ops.stats_fusable(g, ops.dcode(x.dtype)) for g in gs):
             stats = ops._clean_scratch(ops.STAT_SLOTS * pw.Cop * 2, x.device, tag="bn-stats")
-    y = ops.ConvT2dFn.apply(x, pw.weight, pw, k, stride, pad, out_pad, False, stats)
-    return ops.BatchNormActFn.apply(y, bn.weight, bn.bias, bn, training, relu, stats)
+    y = ops.ConvT2dFn.apply(x, pw.weight, pw, k, stride, pad, out_pad, False, stats, _link_of(x))
+    return _bn_apply(y, bn, training, relu, stats)
 
 
 def res_head(x, p1, pd, stride, training):
@@ -234,7 +247,7 @@ def res_head(x, p1, pd, stride, training):
 def conv_bn_act(x, pw, k, stride, pad, bn: nn.BatchNorm2d, training, relu=True):
     """relu?(BatchNorm2d(conv(x))) -- the conv bias has no effect through a batch norm and carries no gradient."""
     y, stats = conv_with_stats(x, pw, k, stride, pad, training)
-    return ops.BatchNormActFn.apply(y, bn.weight, bn.bias, bn, training, relu, stats)
+    return _bn_apply(y, bn, training, relu, stats)
 
 
 def layer_norm(x, ln: nn.LayerNorm):

@@ -114,19 +114,34 @@ def stats_fusable(g, dt):
     return _ws_need(g, dt) == 0
 
 
-def _igemm(src, wgt, bias, dst, g, flags=0, stats=None):
+class BNLink:
+    """Hand-off between a BatchNorm2d(+ReLU) layer and the convolution that consumes its output: that convolution's
+    data-gradient GEMM produces the layer's dy and can add the layer's backward sums in its epilogue (ast_igemm_bn)."""
+    __slots__ = ("x", "scale", "shift", "relu", "table", "filled")
+
+    def __init__(self):
+        self.x = self.scale = self.shift = self.table = None
+        self.relu, self.filled = True, False
+
+
+def _igemm(src, wgt, bias, dst, g, flags=0, stats=None, bn=None):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     need = _ws_need(g, dcode(src.dtype))
-    if stats is not None:                       # [64][Cd][2] slots filled by the epilogue (flags bit 3); never with split-K
+    if bn is not None:                          # [64][Cd][3] slots: BatchNorm-backward sums of the dy this GEMM produces
         assert need == 0 and flags == 0
-        ws, need, flags = stats, stats.numel(), 8
+        check(lib().ast_igemm_bn(ptr(src), ptr(wgt), ptr(bias), ptr(dst), g, dcode(src.dtype), 16 | (0 if bn.relu else 32), ptr(bn.table),
+                                 bn.table.numel(), ptr(bn.x), ptr(bn.scale), ptr(bn.shift), stream()), "ast_igemm_bn")
     else:
-        ws = _clean_scratch(need, src.device) if need > 0 else None    # persistent, handed back zeroed by the finish pass
-        flags |= 4 if need > 0 else 0
-    check(lib().ast_igemm(ptr(src), ptr(wgt), ptr(bias), ptr(dst), g, dcode(src.dtype), flags, ptr(ws), need,
-                          stream()), "ast_igemm")
+        if stats is not None:                   # [64][Cd][2] slots filled by the epilogue (flags bit 3); never with split-K
+            assert need == 0 and flags == 0
+            ws, need, flags = stats, stats.numel(), 8
+        else:
+            ws = _clean_scratch(need, src.device) if need > 0 else None    # persistent, handed back zeroed by the finish pass
+            flags |= 4 if need > 0 else 0
+        check(lib().ast_igemm(ptr(src), ptr(wgt), ptr(bias), ptr(dst), g, dcode(src.dtype), flags, ptr(ws), need,
+                              stream()), "ast_igemm")
     if PROFILE is not None:
         e1.record()
         fl, by = _gemm_cost(g, src.element_size())
@@ -195,13 +210,13 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d on NHWC (style_encoder.py:50-67, new_decoder.py:29-61)."""
 
     @staticmethod
-    def forward(ctx, x, weight, pw: PackedWeight, k, stride, pad, bias_grad, stats=None):
+    def forward(ctx, x, weight, pw: PackedWeight, k, stride, pad, bias_grad, stats=None, link=None):
         N, H, W, Cs = x.shape
         g, (Ho, Wo) = gather_direct(N, H, W, Cs, pw.Cop, k, stride, pad)
         y = torch.empty((N, Ho, Wo, pw.Cop), dtype=x.dtype, device=x.device)
         _igemm(x, pw.wf, pw.bias_ptr_tensor(), y, g, stats=stats)
         ctx.save_for_backward(x)
-        ctx.pw, ctx.geom, ctx.args, ctx.bias_grad = pw, g, (k, stride, pad), bias_grad
+        ctx.pw, ctx.geom, ctx.args, ctx.bias_grad, ctx.link = pw, g, (k, stride, pad), bias_grad, link
         return y
 
     @staticmethod
@@ -219,9 +234,25 @@ class Conv2dFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            for g in gathers_transposed(N, dy.shape[1], dy.shape[2], pw.Cop, H, W, Cs, k, stride, pad):
-                _igemm(dy, pw.wb, None, dx, g)
-        return dx, None, None, None, None, None, None, None
+            gs = gathers_transposed(N, dy.shape[1], dy.shape[2], pw.Cop, H, W, Cs, k, stride, pad)
+            link = _bn_link_ready(ctx.link, gs, x)
+            for g in gs:
+                _igemm(dy, pw.wb, None, dx, g, bn=link)
+            if link is not None:
+                link.filled = True
+        return dx, None, None, None, None, None, None, None, None
+
+
+def _bn_link_ready(link, geoms, x):
+    """The BNLink of a conv input, armed with a zeroed [64][C][3] slot table, when every data-gradient launch can take the
+    fused sums (no split-K plan); else None and the BatchNorm backward runs its own pass."""
+    if link is None or link.x is None or not config.fused_bn_bwd or _SyncBN.world > 1:
+        return None
+    if not all(stats_fusable(g, dcode(x.dtype)) for g in geoms):
+        return None
+    link.table = _clean_scratch(STAT_SLOTS * x.shape[3] * 3, x.device, tag="bn-bwd")
+    return link
+
 
 
 class ResHeadFn(torch.autograd.Function):
@@ -270,7 +301,7 @@ class ConvT2dFn(torch.autograd.Function):
     """nn.ConvTranspose2d on NHWC (new_decoder.py:72-96)."""
 
     @staticmethod
-    def forward(ctx, x, weight, pw: PackedWeight, k, stride, pad, out_pad, bias_grad, stats=None):
+    def forward(ctx, x, weight, pw: PackedWeight, k, stride, pad, out_pad, bias_grad, stats=None, link=None):
         N, H, W, Cs = x.shape
         Ho = (H - 1) * stride - 2 * pad + k + out_pad
         Wo = (W - 1) * stride - 2 * pad + k + out_pad
@@ -279,7 +310,7 @@ class ConvT2dFn(torch.autograd.Function):
         for g in gathers_transposed(N, H, W, Cs, Ho, Wo, pw.Cop, k, stride, pad):
             _igemm(x, pw.wf, b, y, g, stats=stats)        # the parity classes partition the output: their statistics add up
         ctx.save_for_backward(x)
-        ctx.pw, ctx.args, ctx.bias_grad = pw, (k, stride, pad, Ho, Wo), bias_grad
+        ctx.pw, ctx.args, ctx.bias_grad, ctx.link = pw, (k, stride, pad, Ho, Wo), bias_grad, link
         return y
 
     @staticmethod
@@ -300,8 +331,11 @@ class ConvT2dFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _igemm(dy, pw.wb, None, dx, g)
-        return dx, None, None, None, None, None, None, None, None
+            link = _bn_link_ready(ctx.link, (g,), x)
+            _igemm(dy, pw.wb, None, dx, g, bn=link)
+            if link is not None:
+                link.filled = True
+        return dx, None, None, None, None, None, None, None, None, None
 
 
 SKINNY_MAX_ROWS = 64
@@ -558,11 +592,15 @@ class BatchNormActFn(torch.autograd.Function):
     """relu?(BatchNorm2d(x)) with batch statistics (training) or running stats (eval)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn, training, relu, stats=None):
+    def forward(ctx, x, gamma, beta, bn, training, relu, stats=None, link=None):
         N, H, W, C = x.shape
         Creal = gamma.numel()
+        ctx.link = None
         if training:
             mean, rstd, scale, shift = _bn_batch_stats(x, gamma, beta, bn, stats)
+            if link is not None:                # the consumer conv's data gradient may add this layer's backward sums
+                link.x, link.scale, link.shift, link.relu = x, scale, shift, bool(relu)
+                ctx.link = link
         else:
             mean, rstd, scale, shift = _finalize(None, N, H * W, C, Creal, False, gamma, beta, bn.running_mean,
                                                  bn.running_var, True, bn.eps, x.device)
@@ -582,16 +620,25 @@ class BatchNormActFn(torch.autograd.Function):
         dy = dy.contiguous()
         N, H, W, C = x.shape
         gamma, beta = ctx.gamma, ctx.beta
-        sums3 = _clean_scratch(N * C * 3, x.device)
-        check(lib().ast_norm_bwd_sums_pre(ptr(dy), ptr(y), ptr(x), None, ptr(sums3), N, H * W, C, int(ctx.relu),
-                                          dcode(x.dtype), 1, ptr(scale) if pre else None, ptr(shift) if pre else None, None, None,
-                                          stream()), "ast_norm_bwd_sums")
+        link = ctx.link
         k1 = torch.empty((C, 3), dtype=torch.float32, device=x.device)
-        gsum = _global_sums(sums3, N * C * 3) if _SyncBN.world > 1 else None
-        # gamma/beta gradients come from the LOCAL sums (the gradient all-reduce averages them over ranks)
-        check(lib().ast_norm_bwd_finalize(ptr(sums3), 1, N, H * W, C, gamma.numel(), ptr(gamma), ptr(mean), ptr(rstd),
-                                          ptr(acc_grad(gamma)), ptr(acc_grad(beta)), ptr(k1),
-                                          None, None, None, None, None, None, stream()), "ast_norm_bwd_finalize")
+        if link is not None and link.filled:
+            # the data-gradient GEMM that produced dy already added (sum dz, sum dz*x) to the slot table: no pass over dy, x
+            link.filled = False
+            check(lib().ast_norm_bwd_finalize_n(ptr(link.table), 1, STAT_SLOTS, 0, C, gamma.numel(), ptr(gamma), ptr(mean), ptr(rstd),
+                                                ptr(acc_grad(gamma)), ptr(acc_grad(beta)), ptr(k1), None, None, None, None, None, None,
+                                                N * H * W, stream()), "ast_norm_bwd_finalize")
+            gsum = None
+        else:
+            sums3 = _clean_scratch(N * C * 3, x.device)
+            check(lib().ast_norm_bwd_sums_pre(ptr(dy), ptr(y), ptr(x), None, ptr(sums3), N, H * W, C, int(ctx.relu),
+                                              dcode(x.dtype), 1, ptr(scale) if pre else None, ptr(shift) if pre else None, None, None,
+                                              stream()), "ast_norm_bwd_sums")
+            gsum = _global_sums(sums3, N * C * 3) if _SyncBN.world > 1 else None
+            # gamma/beta gradients come from the LOCAL sums (the gradient all-reduce averages them over ranks)
+            check(lib().ast_norm_bwd_finalize(ptr(sums3), 1, N, H * W, C, gamma.numel(), ptr(gamma), ptr(mean), ptr(rstd),
+                                              ptr(acc_grad(gamma)), ptr(acc_grad(beta)), ptr(k1),
+                                              None, None, None, None, None, None, stream()), "ast_norm_bwd_finalize")
         if gsum is not None:        # dx coefficients from the global sums and the global pixel count
             check(lib().ast_norm_bwd_finalize(ptr(gsum), 0, N, H * W * _SyncBN.world, C, gamma.numel(), ptr(gamma), ptr(mean), ptr(rstd),
                                               None, None, ptr(k1), None, None, None, None, None, None, stream()), "ast_norm_bwd_finalize")
@@ -599,7 +646,7 @@ class BatchNormActFn(torch.autograd.Function):
         check(lib().ast_norm_bwd_apply_pre(ptr(dy), ptr(y), ptr(x), None, ptr(k1), None, ptr(dx), None, N, H * W, C,
                                            int(ctx.relu), dcode(x.dtype), ptr(scale) if pre else None, ptr(shift) if pre else None,
                                            None, None, stream()), "ast_norm_bwd_apply")
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
 class ResTailFn(torch.autograd.Function):

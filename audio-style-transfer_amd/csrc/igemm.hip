@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ s
                                                      const ast_gather_t g, const int M, const int flags,
                                                      float* __restrict__ ws, const int kt_per_split, const int cpc_shift,
                                                      const unsigned src_bytes, const unsigned wgt_bytes,
-                                                     const float rcp_hw, const float rcp_w) {
+                                                     const float rcp_hw, const float rcp_w,
+                                                     const T* __restrict__ bn_x, const float* __restrict__ bn_scale,
+                                                     const float* __restrict__ bn_shift) {
   constexpr int E = 16 / sizeof(T);
   constexpr int ES = sizeof(T);
   constexpr int NSUB = KCH / 4;
@@ -314,6 +316,12 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ s
   // statistics of the values it STORES (BatchNorm2d's batch statistics without a second pass over the output);
   // slot = tile index mod 64 keeps the f32 atomics off a single address per channel
   const bool stats = (flags & 8) && !split;
+  // flags bit 4: this launch is the data gradient that produces dy of a BatchNorm(+ReLU) layer whose input x (bn_x, same
+  // geometry as dst) and forward coefficients are given: the tile adds the layer's backward sums (sum dz, sum dz*x, with
+  // dz = dy * [fma(x, scale, shift) > 0]) of the values it stores into the [64][Cd][3] slot table `ws` -- the separate
+  // pass over dy and x (ast_norm_bwd_sums) disappears.  bit 5: the layer has no ReLU (mask = 1).
+  const bool bstats = (flags & 16) && !split;
+  const bool bn_relu = !(flags & 32);
   float st1[TN][4], st2[TN][4];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -356,11 +364,32 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ s
           st1[i][r] += q; st2[i][r] += q * q;
         }
       }
+      if (bstats) {
+        float xv[4];
+        if constexpr (sizeof(T) == 2) {
+          const bf16x4 xq = *reinterpret_cast<const bf16x4*>(bn_x + pix * g.Cd + co);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xv[r] = (float)xq[r];
+        } else {
+          const f32x4 xq = *reinterpret_cast<const f32x4*>(bn_x + pix * g.Cd + co);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xv[r] = xq[r];
+        }
+        // (loading the coefficients once per channel tile ahead of the pixel loop measured slower: register pressure)
+        const f32x4 sc4 = *reinterpret_cast<const f32x4*>(bn_scale + co), sf4 = *reinterpret_cast<const f32x4*>(bn_shift + co);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float q = (float)(T)v[r];
+          const float dz = (!bn_relu || __builtin_fmaf(xv[r], sc4[r], sf4[r]) > 0.f) ? q : 0.f;
+          st1[i][r] += dz; st2[i][r] += dz * xv[r];
+        }
+      }
       store4<T>(drow + co, v, accumulate, relu);
     }
   }
-  if (stats) {
-    float* slot = ws + (size_t)(tix & 63) * g.Cd * 2;
+  if (stats || bstats) {
+    const int KS = bstats ? 3 : 2;                               // floats per channel in the slot table
+    float* slot = ws + (size_t)(tix & 63) * g.Cd * KS;
     // reduce over the 16 pixels of the lane group, then spread the (tile, channel, sum|sumsq) values over the 16 lanes
     // so that ONE atomic instruction per pair of channel tiles carries them all (an atomic costs its issue slot
     // whatever the number of active lanes: 4-lane atomics per value made this slower than the separate pass)
@@ -387,7 +416,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ s
         }
       const int ii = fr >> 3, r = (fr >> 1) & 3, which = fr & 1;
       const int co = bn0 + wn * WTN + (i0 + ii) * 16 + fq * 4 + r;
-      if (i0 + ii < TN && co < g.Cd) unsafeAtomicAdd(slot + (size_t)co * 2 + which, val);
+      if (i0 + ii < TN && co < g.Cd) unsafeAtomicAdd(slot + (size_t)co * KS + which, val);
     }
   }
 }
@@ -850,7 +879,7 @@ int launch_wgrad_halo(const void* dy, const void* src, float* dw, const ast_gath
   return 0;
 }
 
-struct IgemmPlan { int bm, bn, kch, nsplit, kt_per_split, depth, kgroups; };
+struct IgemmPlan { int bm, bn, kch, nsplit, kt_per_split, depth, kgroups; const void* bn_x; const float* bn_scale; const float* bn_shift; };
 
 IgemmPlan plan_igemm(const ast_gather_t& g, int M, int dtype) {
   const int E = dtype == AST_BF16 ? 8 : 4;
@@ -909,7 +938,8 @@ int launch_igemm_ut(const void* src, const void* wgt, const float* bias, void* d
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
   const unsigned wgt_bytes = (unsigned)((size_t)g.Cd * g.wtaps * g.Cs * sizeof(T));
   hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KCH, D, KG, UT>), grid, dim3(256 * KG), LDS, s, (const T*)src, (const T*)wgt, bias, (T*)dst, g, M,
-                     flags, ws, p.kt_per_split, shift, src_bytes, wgt_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm);
+                     flags, ws, p.kt_per_split, shift, src_bytes, wgt_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm,
+                     (const T*)p.bn_x, p.bn_scale, p.bn_shift);
   if (p.nsplit > 1) {
     const size_t total = (size_t)M * (g.Cd >> 2);
     hipLaunchKernelGGL((splitk_finish_kernel<T>), dim3((unsigned)std::min<size_t>((total + 255) / 256, 2048)), dim3(256), 0, s, ws, bias,
@@ -957,14 +987,21 @@ extern "C" int ast_igemm_plan(const ast_gather_t* gp, int dtype, int* out5) {
   return 0;
 }
 
-extern "C" int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t* gp,
-                         int dtype, int flags, float* ws, long ws_floats, void* stream) {
+extern "C" int ast_igemm_bn(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t* gp,
+                            int dtype, int flags, float* ws, long ws_floats, const void* bn_x, const float* bn_scale,
+                            const float* bn_shift, void* stream) {
   if (int rc = check_gather(gp, "ast_igemm")) return rc;
   if (!src || !wgt || !dst) AST_FAIL("ast_igemm: null pointer");
   const ast_gather_t g = *gp;
   const int M = g.N * g.Hm * g.Wm;
   hipStream_t s = (hipStream_t)stream;
   IgemmPlan p = plan_igemm(g, M, dtype);
+  p.bn_x = bn_x; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
+  if (flags & 16) {
+    if (p.nsplit > 1) AST_FAIL("ast_igemm: fused BatchNorm-backward sums are not available for a split-K plan (check ast_igemm_plan)");
+    if ((flags & 11) || !ws || ws_floats < 64L * g.Cd * 3 || !bn_x || !bn_scale || !bn_shift)
+      AST_FAIL("ast_igemm: fused BatchNorm-backward sums need plain stores, a zeroed [64][Cd][3] table and the layer's x / scale / shift");
+  }
   if (p.nsplit > 1 && (!ws || ws_floats < (long)M * g.Cd)) AST_FAIL("ast_igemm: split-K needs a workspace of %ld floats (ast_igemm_ws_floats)", (long)M * g.Cd);
   if (flags & 8) {
     if (p.nsplit > 1) AST_FAIL("ast_igemm: fused channel statistics are not available for a split-K plan (check ast_igemm_plan)");
@@ -988,6 +1025,11 @@ extern "C" int ast_igemm(const void* src, const void* wgt, const float* bias, vo
 #undef AST_IG
 #undef AST_IG4
   return 0;
+}
+
+extern "C" int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t* gp,
+                         int dtype, int flags, float* ws, long ws_floats, void* stream) {
+  return ast_igemm_bn(src, wgt, bias, dst, gp, dtype, flags & ~48, ws, ws_floats, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t* gp, int dtype, void* stream) {

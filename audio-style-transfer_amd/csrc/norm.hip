@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(float* __restric
                                          const float* gamma1, const float* mean1, const float* rstd1,
                                          float* dgamma1, float* dbeta1, float* k1,
                                          const float* gamma2, const float* mean2, const float* rstd2,
-                                         float* dgamma2, float* dbeta2, float* k2) {
+                                         float* dgamma2, float* dbeta2, float* k2, long count) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   const bool real = c < Creal;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(float* __restric
   if (lane != 0) return;
   if (k1) {
     if (real) {
-      const double P = (double)N * HW, g = gamma1[c], m = mean1[c], r = rstd1[c];
+      const double P = count > 0 ? (double)count : (double)N * HW, g = gamma1[c], m = mean1[c], r = rstd1[c];   // count > 0: rows are slots
       const double Q = r * (S1 - m * S0);
       if (dgamma1) dgamma1[c] += (float)Q;
       if (dbeta1) dbeta1[c] += (float)S0;
@@ -585,15 +585,23 @@ extern "C" int ast_norm_bwd_sums(const void* dy, const void* y, const void* x, c
   return ast_norm_bwd_sums_pre(dy, y, x, r, sums3, N, HW, C, relu, dtype, assume_zeroed, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
+extern "C" int ast_norm_bwd_finalize_n(float* sums3, int zero_sums, int N, int HW, int C, int Creal, const float* gamma1,
+                                     const float* mean1, const float* rstd1, float* dgamma1, float* dbeta1, float* k1,
+                                     const float* gamma2, const float* mean2, const float* rstd2, float* dgamma2,
+                                     float* dbeta2, float* k2, long count, void* stream) {
+  if (!sums3 || (k1 && (!gamma1 || !mean1 || !rstd1)) || (k2 && (!gamma2 || !mean2 || !rstd2))) AST_FAIL("ast_norm_bwd_finalize: bad args");
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums3, zero_sums, N, HW, C, Creal,
+                     gamma1, mean1, rstd1, dgamma1, dbeta1, k1, gamma2, mean2, rstd2, dgamma2, dbeta2, k2, count);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int ast_norm_bwd_finalize(float* sums3, int zero_sums, int N, int HW, int C, int Creal, const float* gamma1,
                                      const float* mean1, const float* rstd1, float* dgamma1, float* dbeta1, float* k1,
                                      const float* gamma2, const float* mean2, const float* rstd2, float* dgamma2,
                                      float* dbeta2, float* k2, void* stream) {
-  if (!sums3 || (k1 && (!gamma1 || !mean1 || !rstd1)) || (k2 && (!gamma2 || !mean2 || !rstd2))) AST_FAIL("ast_norm_bwd_finalize: bad args");
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums3, zero_sums, N, HW, C, Creal,
-                     gamma1, mean1, rstd1, dgamma1, dbeta1, k1, gamma2, mean2, rstd2, dgamma2, dbeta2, k2);
-  AST_CHECK_LAUNCH();
-  return 0;
+  return ast_norm_bwd_finalize_n(sums3, zero_sums, N, HW, C, Creal, gamma1, mean1, rstd1, dgamma1, dbeta1, k1, gamma2, mean2, rstd2,
+                                 dgamma2, dbeta2, k2, 0, stream);
 }
 
 extern "C" int ast_norm_bwd_apply_pre(const void* dy, const void* y, const void* x, const void* r, const float* k1,

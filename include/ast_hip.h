@@ -62,6 +62,12 @@ typedef struct ast_gather_t {
  * and plain stores (bits 0 and 1 clear); reduce with ast_norm_finalize(N = 64, count = pixels). */
 int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst,
               const ast_gather_t* g, int dtype, int flags, float* ws, long ws_floats, void* stream);
+/* ast_igemm as the data-gradient GEMM that PRODUCES dy of a BatchNorm2d(+ReLU) layer (flags bit 4; bit 5: no ReLU):
+ * bn_x is that layer's input (same geometry and dtype as dst), bn_scale/bn_shift its forward coefficients; every tile adds
+ * (sum dz, sum dz*x), dz = dy*[fma(x, scale, shift) > 0], of the values it stores into the zeroed [64][Cd][3] table `ws`,
+ * so ast_norm_bwd_sums need not run (reduce with ast_norm_bwd_finalize(N = 64, count = pixels)).  Plans without split-K. */
+int ast_igemm_bn(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t* g, int dtype, int flags,
+                 float* ws, long ws_floats, const void* bn_x, const float* bn_scale, const float* bn_shift, void* stream);
 /* f32 workspace (floats) ast_igemm needs for this geometry: >0 when the launch is split over K
  * (under-filled grids of the deep, small-M layers), 0 otherwise, <0 on a bad geometry. */
 long ast_igemm_ws_floats(const ast_gather_t* g, int dtype);
@@ -171,6 +177,11 @@ int ast_norm_bwd_finalize(float* sums3, int zero_sums, int N, int HW, int C, int
                           float* dgamma1, float* dbeta1, float* k1,
                           const float* gamma2, const float* mean2, const float* rstd2,
                           float* dgamma2, float* dbeta2, float* k2, void* stream);
+/* count > 0: the N rows of sums3 are partial-sum slots (the [64][C][3] table filled by ast_igemm_bn) over `count` pixels */
+int ast_norm_bwd_finalize_n(float* sums3, int zero_sums, int N, int HW, int C, int Creal, const float* gamma1,
+                            const float* mean1, const float* rstd1, float* dgamma1, float* dbeta1, float* k1,
+                            const float* gamma2, const float* mean2, const float* rstd2, float* dgamma2,
+                            float* dbeta2, float* k2, long count, void* stream);
 /* dx = k1[c][0]*dz + k1[c][1]*x + k1[c][2];  dr = k2[n][c][0]*dz + k2[n][c][1]*r + k2[n][c][2] */
 int ast_norm_bwd_apply(const void* dy, const void* y, const void* x, const void* r,
                        const float* k1, const float* k2, void* dx, void* dr,
