@@ -13,9 +13,9 @@ for _ in range(2): tr.step(x, labels)
 torch.cuda.synchronize()
 recs = []
 orig_ig, orig_wg = ops._igemm, ops._wgrad
-def ig(src, wgt, bias, dst, g, flags=0, stats=None):
+def ig(src, wgt, bias, dst, g, flags=0, stats=None, bn=None):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); orig_ig(src, wgt, bias, dst, g, flags, stats); e1.record()
+    e0.record(); orig_ig(src, wgt, bias, dst, g, flags, stats, bn); e1.record()
     M = g.N*g.Hm*g.Wm
     recs.append(("igemm " + ops._igemm_config(g, ops.dcode(src.dtype)) + (" f32" if src.dtype == torch.float32 else ""), M, g.Cd, g.ntaps*g.Cs, g.ntaps, ops._gemm_cost(g, src.element_size()), e0, e1))
 def wg(dy, src, dwp, g):
