@@ -236,6 +236,32 @@ def test_error_surface():
         ast_amd.StyleEncoder()(torch.randn(1, 1, 2, 287, 597))        # CPU tensors: no fallback
 
 
+@pytest.mark.parametrize("B,S", [(2, 3), (6, 1)])
+def test_step_f32_vs_oracle_other_shapes(B, S):
+    """BASELINE configs[4] shapes (variable clip length: S = 1..3 sections; an odd number of rows per class): forward,
+    every loss scalar and the whole-model gradient against the on-box oracle (no golden file for these shapes)."""
+    config.set_compute_dtype(torch.float32)
+    ms = build_models()
+    x = sp.seeded_input(B, S).to(DEV)
+    labels = sp.balanced_labels(B)
+    r = hip_step(ms, x, labels)
+    o = oracle_step(B, S)
+    assert rel_err(r["style"], o["style"]) < 1e-3 and rel_err(r["content"], o["content"]) < 1e-3
+    assert rel_err(r["out"], o["out"]) < 1e-3
+    for k in ("total_loss", "mse_loss", "mag_loss", "phase_loss", "temporal_loss", "spectral_loss"):
+        assert math.isclose(float(r["rec"][k]), float(o["rec"][k]), rel_tol=1e-3, abs_tol=1e-6), k
+    assert math.isclose(float(r["total"]), float(o["total"]), rel_tol=1e-3)
+    for tag in ("style", "content", "decoder"):
+        num = den = 0.0
+        for k, p in ms[tag].named_parameters():
+            ref = o["sds"][tag][k].grad
+            if ref is None or p.grad is None:
+                continue
+            num += float((p.grad.double().cpu() - ref.double()).pow(2).sum())
+            den += float(ref.double().pow(2).sum())
+        assert math.sqrt(num / den) < 1e-2, (tag, math.sqrt(num / den))
+
+
 def test_simple_decoder_f32_vs_golden(golden_dir):
     """SimpleDecoder_TransformerOnly.Decoder against the real reference's fixtures: teacher-forced
     output, the 1.0-MSE-weight loss, gradient norms and strided samples of the two 301 MB weight gradients, and the
