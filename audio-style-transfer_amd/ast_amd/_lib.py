@@ -91,6 +91,7 @@ _SIGS = {
     "ast_hsic": ([vp, vp, i32, i32, vp, vp, vp, vp, vp], i32),
     "ast_crosscov": ([vp, vp, i32, i32, vp, vp, vp, vp, vp], i32),
     "ast_istft": ([vp, i32, i32, vp, vp, vp], i32),
+    "ast_bin_stats_acc": ([vp, vp, vp, i32, i32, i32, vp], i32),
     "ast_zscore": ([vp, vp, vp, vp, i32, i32, i32, f32, vp], i32),
     "ast_sections_overlap_avg": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "ast_cross_entropy": ([vp, vp, i32, i32, vp, vp, vp], i32),

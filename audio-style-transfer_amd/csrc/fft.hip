@@ -176,6 +176,31 @@ __global__ __launch_bounds__(256) void zscore_kernel(const float* __restrict__ x
 }
 }  // namespace
 
+namespace {
+// Preprocessing_Dataset/compute_unified_stats.py:34-44 for one clip: per (channel, bin) mean over the T frames and the
+// unbiased variance (torch.std(dim=1)**2), ADDED into running sums (the caller divides by the clip count at the end).
+// One thread per (channel, bin); consecutive threads read consecutive bins of a frame (coalesced).
+__global__ __launch_bounds__(256) void bin_stats_kernel(const float* __restrict__ x, float* __restrict__ mean_acc,
+                                                        float* __restrict__ var_acc, int T, int F) {
+  const int f = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  if (f >= F) return;
+  const float* p = x + (size_t)c * T * F + f;
+  double s = 0.0, q = 0.0;
+  for (int t = 0; t < T; ++t) { const double v = p[(size_t)t * F]; s += v; q += v * v; }
+  const double m = s / T;
+  const double var = T > 1 ? fmax((q - s * m) / (T - 1), 0.0) : 0.0;
+  mean_acc[(size_t)c * F + f] += (float)m;
+  var_acc[(size_t)c * F + f] += (float)var;
+}
+}  // namespace
+
+extern "C" int ast_bin_stats_acc(const float* x, float* mean_acc, float* var_acc, int C, int T, int F, void* stream) {
+  if (!x || !mean_acc || !var_acc || C < 1 || T < 1 || F < 1) AST_FAIL("ast_bin_stats_acc: bad args");
+  hipLaunchKernelGGL(bin_stats_kernel, dim3((F + 255) / 256, C), dim3(256), 0, (hipStream_t)stream, x, mean_acc, var_acc, T, F);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int ast_zscore(const float* x, const float* mean, const float* std_, float* out, int C, int T, int F, float eps, void* stream) {
   if (!x || !mean || !std_ || !out || C < 1 || T < 1 || F < 1) AST_FAIL("ast_zscore: bad args");
   const size_t total = (size_t)C * T * F;

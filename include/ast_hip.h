@@ -299,6 +299,9 @@ int ast_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, 
 int ast_istft(const float* spec, int Bc, int T, float* frames_ws, float* wave, void* stream);
 /* sections2spectrogram (utilityFunctions.py:265-283): sections (Bc,S,2,wind,F_in) -> out (Bc,2,out_T,F_out), the
  * count-normalised overlap-average at step `hop`, bins [0,F_out) only, truncated to out_T <= hop*(S-1)+wind frames. */
+/* Dataset statistics, one clip at a time (Preprocessing_Dataset/compute_unified_stats.py:34-44): per (channel, bin) mean over
+ * the T frames and unbiased variance of a contiguous (C,T,F) f32 spectrogram, ADDED into mean_acc / var_acc (C*F floats). */
+int ast_bin_stats_acc(const float* x, float* mean_acc, float* var_acc, int C, int T, int F, void* stream);
 /* normalize (dataloader.py:9-13): out = (x - mean[c][f]) / (std[c][f] + eps) over a contiguous (C,T,F) f32 spectrogram */
 int ast_zscore(const float* x, const float* mean, const float* std_, float* out, int C, int T, int F, float eps, void* stream);
 int ast_sections_overlap_avg(const float* sections, float* out, int Bc, int S, int wind, int hop, int F_in, int F_out,

@@ -680,3 +680,35 @@ def test_dataloader_itemwise_api_matches_fused_frontend_and_oracle(tmp_path):
         dl.dataset[0]
     with pytest.raises(ValueError):
         DL.normalize(torch.zeros(2, 3, device=DEV), mean, std)
+
+
+def test_checkpoint_layout_and_stft_stats(tmp_path):
+    """the reference's four-state_dict .pth layout round-trips through the modules (same keys as the
+    oracle's hand-written reference layouts), and the streaming STFT statistics equal compute_unified_stats.py's recipe."""
+    from ast_amd import checkpoint as CK
+    from oracle import layout as OL
+    mods = {"content_encoder": ast_amd.ContentEncoder(), "style_encoder": ast_amd.StyleEncoder(), "decoder": ast_amd.Decoder(),
+            "discriminator": ast_amd.Discriminator()}
+    for m in mods.values():
+        m.to(DEV)
+    path = str(tmp_path / "ckpt.pth")
+    CK.save_checkpoint(path, mods["content_encoder"], mods["style_encoder"], mods["decoder"], mods["discriminator"], epoch=3)
+    raw = torch.load(path, map_location="cpu")
+    for key, tag in (("content_encoder", "content"), ("style_encoder", "style"), ("decoder", "decoder"), ("discriminator", "disc")):
+        assert list(raw[key].keys()) == list(OL.LAYOUTS[tag]().keys()), key         # reference key order and names
+    fresh = {k: type(m)().to(DEV) for k, m in mods.items()}
+    ck = CK.load_checkpoint(path, fresh["content_encoder"], fresh["style_encoder"], fresh["decoder"], fresh["discriminator"])
+    assert ck["epoch"] == 3
+    for k in mods:
+        for (n1, t1), (n2, t2) in zip(mods[k].state_dict().items(), fresh[k].state_dict().items()):
+            assert n1 == n2 and torch.equal(t1, t2), (k, n1)
+    st = CK.StftStats(DEV)
+    means, variances = [], []
+    for i in range(3):
+        w = torch.from_numpy(FO.synth_waveform(i, "piano" if i % 2 == 0 else "violin", seconds=2.0 + i))
+        st.add(w)
+        spec = torch.from_numpy(FO.stft(w.numpy()))                          # (2, T, 513) by the oracle
+        means.append(spec.mean(dim=1)); variances.append(spec.std(dim=1) ** 2)
+    mean, std = st.finalize()
+    assert rel_err(mean, torch.stack(means).mean(0)) < 1e-4
+    assert rel_err(std, torch.stack(variances).mean(0).sqrt()) < 1e-4
