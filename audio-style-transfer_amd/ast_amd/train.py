@@ -57,6 +57,7 @@ class TrainConfig:
     decoder: str = "new"          # "new" = new_decoder.Decoder (north star); "simple" = SimpleDecoder_TransformerOnly.Decoder (8(f)1)
     grad_wire: str = "auto"       # dtype of the gradient all-reduce: "f32", "bf16", or "auto" = bf16 in the bf16 compute
                                   # mode over RCCL, else f32 (env AST_GRAD_WIRE overrides)
+    overlap_d: bool = True        # one GPU: discriminator phase on its own stream beside the decoder forward
     keep_grads: bool = False      # eager mode: keep a copy of the (all-reduced) generator gradient for tests
 
 
@@ -158,6 +159,7 @@ class Trainer:
             ops.set_sync_bn(world)
             self.cfg = dataclasses.replace(self.cfg, use_graph=False, multi_stream=False)
         self._glob = None
+        self._stream_d = None
         self._graphs = {}
         self._streams = None
         self._y_emb = None
@@ -168,7 +170,7 @@ class Trainer:
         self.losses = {}
 
     # ------------------------------------------------------------------ one eager step
-    def _forward_backward(self, x, labels_host):
+    def _forward_backward(self, x, labels_host, defer_d=False):
         c = self.cfg
         self.G.zero_grad()
         self.D.zero_grad()
@@ -210,16 +212,22 @@ class Trainer:
             style_emb, class_emb = self.style(x, labels_host)
             content_emb = self.content(x)
         self._y_emb = y_emb
-        # ---- D phase (losses.py:69-79 compute_for_discriminator=True)
+        if defer_d:
+            return y, style_emb, class_emb, content_emb, None
+        d_loss = self._d_phase(style_emb, class_emb, content_emb, labels_host)
+        return y, style_emb, class_emb, content_emb, d_loss
+
+    def _d_phase(self, style_emb, class_emb, content_emb, labels_host):
+        """Discriminator step on the detached embeddings (losses.py:69-79 compute_for_discriminator=True)."""
         bank_d = _module_bank(self.disc)
         bank_d.prepare(True)
         bank_d.hold = True
         d_loss, _ = adversarial_loss(style_emb.detach(), class_emb.detach(), content_emb.detach(), self.disc, labels_host, True)
         d_loss.backward()
         bank_d.hold = False
-        return y, style_emb, class_emb, content_emb, d_loss
+        return d_loss
 
-    def _g_phase(self, x, y, labels_host, style_emb, class_emb, content_emb):
+    def _g_phase(self, x, y, labels_host, style_emb, class_emb, content_emb, before_adv=None):
         c = self.cfg
 
         def wt(w, t):                     # a weight of exactly 1.0 needs no multiply launch (forward and backward)
@@ -245,6 +253,8 @@ class Trainer:
             hs = disentanglement_loss(style_b, content_b)
             total = total + wt(c.w_hsic, hs)
             parts["hsic"] = hs.detach()
+        if before_adv is not None:
+            before_adv()                  # join the stream that ran the D phase and D's Adam step
         if c.use_adv:
             bank_d = _module_bank(self.disc)
             bank_d.prepare(True)          # D weights changed in the D phase
@@ -275,7 +285,33 @@ class Trainer:
         c = self.cfg
         self.G.adam(c.lr_g, c.betas, c.eps, c.max_grad_norm)
 
+    def _step_overlapped(self, x, labels_host):
+        """One GPU, one graph: the discriminator phase (D forward/backward + D's Adam) runs on its own stream beside the
+        decoder forward and the D-independent losses; the streams join before the generator's adversarial term, which
+        needs the updated discriminator (same arithmetic and order of updates as _step_body)."""
+        c = self.cfg
+        self._run_frontend(x)
+        y, style_emb, class_emb, content_emb, _ = self._forward_backward(x, labels_host, defer_d=True)
+        main = torch.cuda.current_stream()
+        if self._stream_d is None:
+            self._stream_d = torch.cuda.Stream(device=self.device)
+        sd = self._stream_d
+        sd.wait_stream(main)
+        with torch.cuda.stream(sd):
+            d_loss = self._d_phase(style_emb, class_emb, content_emb, labels_host)
+            self.D.adam(c.lr_d, c.betas, c.eps, c.max_grad_norm)
+            self.D.zero_grad()
+        d_loss.record_stream(main)
+        self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb, before_adv=lambda: main.wait_stream(sd))
+        self._parts["adv_d"] = d_loss.detach()
+        if c.keep_grads:
+            self.last_grad_g = self.G.flat_g.clone()
+        self.G.adam(c.lr_g, c.betas, c.eps, c.max_grad_norm)
+        return self._parts
+
     def _step_body(self, x, labels_host):
+        if self.world == 1 and not self.cfg.segmented and self.cfg.multi_stream and self.cfg.overlap_d:
+            return self._step_overlapped(x, labels_host)
         self._seg_a(x, labels_host)
         self.D.all_reduce(self.world)
         self._seg_b(x, labels_host)

@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--decoder", default="new", choices=["new", "simple"],
                     help="new_decoder.Decoder (north star) or SimpleDecoder_TransformerOnly.Decoder (SURVEY 8(f)1, 182 M parameters)")
     ap.add_argument("--single-stream", action="store_true", help="capture the three encoder branches on one stream (A/B of the fork/join capture)")
+    ap.add_argument("--no-overlap-d", action="store_true", help="run the discriminator phase in line instead of beside the decoder forward (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -186,7 +187,7 @@ def main():
     import ast_amd
     from ast_amd import train
     ast_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-    tr = train.Trainer(train.TrainConfig(use_graph=not args.no_graph, loss_matched=args.loss_matched, decoder=args.decoder, multi_stream=not args.single_stream), device=dev, rank=rank, world=world)
+    tr = train.Trainer(train.TrainConfig(use_graph=not args.no_graph, loss_matched=args.loss_matched, decoder=args.decoder, multi_stream=not args.single_stream, overlap_d=not args.no_overlap_d), device=dev, rank=rank, world=world)
     clip_seconds = {1: 3.0, 2: CLIP_SECONDS, 3: 8.0, 4: 10.0}[args.sections]   # clip length that yields S sections
     if args.no_frontend:
         x, labels = train.synthetic_batch(args.batch, args.sections, dev, seed=1000 + rank)
