@@ -262,22 +262,34 @@ class Trainer:
         rec = self._rec_loss(out, y)
         total = wt(c.w_rec, rec["total_loss"])
         parts = {"rec": rec["total_loss"].detach()}
+        def adv_term():
+            bank_d = _module_bank(self.disc)
+            bank_d.prepare(True)          # D weights changed in the D phase
+            bank_d.hold = True
+            _, g = adversarial_loss(style_emb, class_emb, content_emb, self.disc, labels_host, False)
+            bank_d.hold = False
+            return g
+
+        g_adv = None
         if side is not None and aux is None:
-            # created AFTER the decoder's nodes, so the autograd engine runs their backward BEFORE the decoder's, on the side stream
+            # The embedding losses and the generator's adversarial term run on the side stream (behind the D phase and D's
+            # Adam step, which the adversarial term needs anyway).  They are created AFTER the decoder's nodes, so the
+            # autograd engine runs their backward BEFORE the decoder's -- on the side stream, beside it.
             with torch.cuda.stream(side):
                 aux = self._aux_losses(labels_host, style_emb, class_emb, content_emb)
+                if c.use_adv:
+                    g_adv = adv_term()
             aux[0].record_stream(torch.cuda.current_stream())
+            if g_adv is not None:
+                g_adv.record_stream(torch.cuda.current_stream())
         if before_adv is not None:
-            before_adv()                  # join the stream that ran the D phase, D's Adam step and the embedding losses
+            before_adv()                  # join the side stream
         aux_total, aux_parts = aux if aux is not None else self._aux_losses(labels_host, style_emb, class_emb, content_emb)
         total = total + aux_total
         parts.update(aux_parts)
         if c.use_adv:
-            bank_d = _module_bank(self.disc)
-            bank_d.prepare(True)          # D weights changed in the D phase
-            bank_d.hold = True
-            _, g_adv = adversarial_loss(style_emb, class_emb, content_emb, self.disc, labels_host, False)
-            bank_d.hold = False
+            if g_adv is None:
+                g_adv = adv_term()
             total = total + wt(c.w_adv, g_adv)
             parts["adv_g"] = g_adv.detach()
         total.backward()
