@@ -304,9 +304,21 @@ class Trainer:
     def _seg_b(self, x, labels_host):
         c = self.cfg
         y, style_emb, class_emb, content_emb, d_loss = self._carry
-        self.D.adam(c.lr_d, c.betas, c.eps, c.max_grad_norm)
-        self.D.zero_grad()
-        self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb)
+        if c.multi_stream and c.overlap_d:
+            # D's Adam step, the embedding losses and the generator's adversarial term beside the decoder (see _step_overlapped)
+            main = torch.cuda.current_stream()
+            if self._stream_d is None:
+                self._stream_d = torch.cuda.Stream(device=self.device)
+            sd = self._stream_d
+            sd.wait_stream(main)
+            with torch.cuda.stream(sd):
+                self.D.adam(c.lr_d, c.betas, c.eps, c.max_grad_norm)
+                self.D.zero_grad()
+            self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb, before_adv=lambda: main.wait_stream(sd), side=sd)
+        else:
+            self.D.adam(c.lr_d, c.betas, c.eps, c.max_grad_norm)
+            self.D.zero_grad()
+            self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb)
         self._parts["adv_d"] = d_loss.detach()
         self._carry = None
 
