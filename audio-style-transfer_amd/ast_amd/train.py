@@ -189,13 +189,18 @@ class Trainer:
             ops.cached_nhwc(x, config.compute_dtype)          # shared input conversion, before the fork
             for st in self._streams:
                 st.wait_stream(main)
-            with torch.cuda.stream(s1):
-                style_emb, class_emb = self.style(x, labels_host)
-            with torch.cuda.stream(s2):
-                content_emb = self.content(x)
-            with torch.cuda.stream(s3):
-                if not self._simple:
-                    y_emb = self.decoder.encode_target(y)
+            order = os.environ.get("AST_BRANCH_ORDER", "ysc")   # creation order = reverse backward priority; y first measured 0.03 ms better
+            for b in order:
+                if b == "s":
+                    with torch.cuda.stream(s1):
+                        style_emb, class_emb = self.style(x, labels_host)
+                elif b == "c":
+                    with torch.cuda.stream(s2):
+                        content_emb = self.content(x)
+                else:
+                    with torch.cuda.stream(s3):
+                        if not self._simple:
+                            y_emb = self.decoder.encode_target(y)
             for st in self._streams:
                 main.wait_stream(st)
             for t in (style_emb, class_emb, content_emb, y_emb):
