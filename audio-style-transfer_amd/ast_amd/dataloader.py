@@ -4,9 +4,9 @@ get_dataloader, with the reference's signatures, warnings and batch layout.
 The per-item path of the reference (dataloader.py:94-121) is decode -> STFT -> CQT -> normalize -> concat -> windows on
 the CPU.  On this path STFT + normalize + windowing + collate layout are ONE kernel over a batch of resident waveforms
 (`utilityFunctions.stft_sections`, used by `train.Trainer.set_frontend`); the functions here keep the item-wise API for
-callers that want it.  File decoding (`load_audio`: torchaudio) and the CQT (`get_CQT`: librosa) are parity-unpinned
-and not built: `DualInstrumentDataset` therefore takes optional `load_audio=` / `get_cqt=` callables and raises
-NotImplementedError without them."""
+callers that want it.  File decoding + resampling (`load_audio`: torchaudio) and the CQT (`get_CQT`: librosa) are the
+device restatements of cqt.py (parity unpinned -- neither library exists in any image); `DualInstrumentDataset` takes
+optional `load_audio=` / `get_cqt=` callables for callers that have the real libraries."""
 from __future__ import annotations
 
 import os
@@ -84,13 +84,10 @@ class DualInstrumentDataset(Dataset):
         return self.length
 
     def _item(self, path, which):
-        if self._load_audio is None or self._get_cqt is None:
-            raise NotImplementedError("DualInstrumentDataset: pass load_audio= and get_cqt= callables; torchaudio decoding and librosa's CQT are "
-                                      "parity-unpinned and not built on this path")
-        audio, _ = self._load_audio(path)
+        audio, _ = (self._load_audio or U.load_audio)(path)
         audio = audio.to(self.device)
         stft = normalize(U.get_STFT(audio), getattr(self, f"stft_mean_{which}"), getattr(self, f"stft_std_{which}"))
-        cqt = normalize(self._get_cqt(audio).to(self.device), getattr(self, f"cqt_mean_{which}"), getattr(self, f"cqt_std_{which}"))
+        cqt = normalize((self._get_cqt or U.get_CQT)(audio).to(self.device), getattr(self, f"cqt_mean_{which}"), getattr(self, f"cqt_std_{which}"))
         return U.get_overlap_windows(concat_stft_cqt(stft, cqt))
 
     def __getitem__(self, idx):

@@ -166,6 +166,7 @@ class Trainer:
         self._carry = None
         self._parts = None
         self._frontend = None
+        self._frontend_cqt = None
         self._static = None
         self.losses = {}
 
@@ -370,11 +371,12 @@ class Trainer:
         return self._parts
 
     # ------------------------------------------------------------------ public API
-    def set_frontend(self, waves, mean, std):
+    def set_frontend(self, waves, mean, std, cqt_mean=None, cqt_std=None):
         """Make the STFT front-end part of the step: every step() first runs the fused STFT + z-score +
         sectioning kernel (utilityFunctions.py:12-37,240-263; dataloader.py:9-13) from these device-resident
         waveforms straight into bins [0,513) of x (the collate layout of dataloader.py:123-147)."""
         self._frontend = (waves.contiguous(), mean.contiguous(), std.contiguous())
+        self._frontend_cqt = None if cqt_mean is None else (cqt_mean.contiguous(), cqt_std.contiguous())
 
     def _run_frontend(self, x):
         if self._frontend is None:
@@ -382,6 +384,9 @@ class Trainer:
         from .utilityFunctions import stft_sections
         waves, mean, std = self._frontend
         stft_sections(waves, mean, std, n_sections=x.shape[1], F_total=x.shape[-1], out=x)
+        if self._frontend_cqt is not None:
+            from .cqt import cqt_sections
+            cqt_sections(waves, x, *self._frontend_cqt)
 
     def step(self, x: torch.Tensor, labels_host: torch.Tensor):
         """x: (B,S,2,287,597) f32 on the device; labels on the HOST (balanced [0]*B/2+[1]*B/2 as

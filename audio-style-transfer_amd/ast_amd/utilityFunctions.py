@@ -2,8 +2,8 @@
 
 get_STFT runs the LDS-staged radix-4 FFT kernel; get_overlap_windows /
 sections2spectrogram / concat_stft_cqt are index plumbing on device tensors.
-inverse_STFT runs an inverse-FFT + overlap-add kernel pair.  get_CQT / inverse_CQT (librosa arithmetic,
-parity unpinned) and load_audio (torchaudio decode) are not provided in this round.
+inverse_STFT runs an inverse-FFT + overlap-add kernel pair.  get_CQT and load_audio live in cqt.py (librosa /
+torchaudio arithmetic restated from their published algorithms: parity unpinned); inverse_CQT is not built.
 """
 from __future__ import annotations
 
@@ -120,5 +120,8 @@ def inverse_STFT_batch(spec):
     return wave
 
 
-def get_CQT(*a, **k):
-    raise NotImplementedError("get_CQT: librosa's CQT is parity-unpinned (no librosa in any build/run image); not built in this round")
+from .cqt import get_CQT, load_audio, resample, cqt_batch, cqt_sections  # noqa: E402,F401  (utilityFunctions.py:39-60,105-122)
+
+
+def inverse_CQT(*a, **k):
+    raise NotImplementedError("inverse_CQT (librosa.icqt, utilityFunctions.py:84-103) is off the train/inference path and not built")

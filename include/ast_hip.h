@@ -309,6 +309,23 @@ int ast_sections_overlap_avg(const float* sections, float* out, int Bc, int S, i
 int ast_stft_sections(const float* wave, int Bc, int nsamp, const float* mean, const float* std_,
                       float* x, int S, int win, int step, int F_total, void* stream);
 
+/* One octave of get_CQT (utilityFunctions.py:39-60 -> librosa.cqt): out[b][0|1][t][bin0+k] = Re|Im( scale[k] *
+ * sum_i y[b][t*hop - nfft/2 + i] * (w_re + i w_im)[k][i] ), y = 0 outside [0,n) (librosa pad_mode="constant").
+ * y (B rows of pitch y_stride floats), w_* (nf, nfft), out (B, 2, T, ld) f32.  The kernels w fold librosa's
+ * rectangular-window STFT and its sparsified wavelet FFT basis (built on the host, ast_amd/cqt.py). */
+int ast_cqt_octave(const float* y, int B, int n, long y_stride, const float* w_re, const float* w_im, const float* scale,
+                   int nf, int nfft, int hop, float* out, int T, int ld, int bin0, void* stream);
+/* normalize + get_overlap_windows of the CQT planes (dataloader.py:9-18, utilityFunctions.py:240-263) into the bins behind
+ * the STFT's: x[b][s][c][w][bin0+k] = (cqt[b][c][s*step+w][k] - mean[c][k]) / (std[c][k] + 1e-8), 0 past frame T-1.
+ * cqt (Bc,2,T,nb), x (Bc,S,2,win,F_total) f32.  The CQT twin of ast_stft_sections. */
+int ast_cqt_sections(const float* cqt, int Bc, int T, int nb, const float* mean, const float* std_, float* x, int S, int win,
+                     int step, int F_total, int bin0, void* stream);
+/* Polyphase FIR resampler: y[b][i*nnew + p] = gain * sum_k kern[p][k] * x[b][i*orig + k - width], x = 0 outside [0,n);
+ * kern (nnew, klen), y (B, m).  Replaces torchaudio.functional.resample in load_audio (utilityFunctions.py:116-117;
+ * kern = its sinc_interp_hann bank) and the halving resample between CQT octaves (orig=2, nnew=1). */
+int ast_resample_poly(const float* x, int B, int n, const float* kern, int orig, int nnew, int klen, int width, float* y, int m,
+                      float gain, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -676,10 +676,129 @@ def test_dataloader_itemwise_api_matches_fused_frontend_and_oracle(tmp_path):
             (tmp_path / d / f"{i}.wav").write_bytes(b"")
     dl = DL.get_dataloader(str(tmp_path / "p"), str(tmp_path / "v"), batch_size=3, shuffle=False)
     assert dl.batch_size == 2 and len(dl.dataset) == 3
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(Exception):                         # empty files are not audio (wave.Error / EOFError)
         dl.dataset[0]
     with pytest.raises(ValueError):
         DL.normalize(torch.zeros(2, 3, device=DEV), mean, std)
+
+
+def _write_wav(path, data, sr, width=2):
+    """data (channels, n) float in [-1, 1) -> PCM WAV"""
+    import wave
+    q = np.clip(np.round(data.T * (1 << (8 * width - 1))), -(1 << (8 * width - 1)), (1 << (8 * width - 1)) - 1).astype(np.int64)
+    if width == 2:
+        raw = q.astype("<i2").tobytes()
+    else:
+        raw = b"".join(int(v).to_bytes(3, "little", signed=True) for v in q.reshape(-1))
+    with wave.open(str(path), "wb") as f:
+        f.setnchannels(data.shape[0]); f.setsampwidth(width); f.setframerate(sr); f.writeframes(raw)
+    return q.T.astype(np.float64) / (1 << (8 * width - 1))
+
+
+@pytest.mark.parametrize("seconds", [2.0, 4.0])
+def test_cqt_matches_oracle(seconds):
+    """get_CQT (utilityFunctions.py:39-60) on the device against oracle/cqt_oracle.py (librosa's published algorithm,
+    float64; PARITY UNPINNED -- no librosa anywhere).  f32 correlations over <= 256 taps: 2e-5 of the peak magnitude."""
+    from ast_amd import utilityFunctions as U
+    from oracle import cqt_oracle as CO
+    waves = np.stack([FO.synth_waveform(i, "piano" if i % 2 == 0 else "violin", seconds=seconds).reshape(-1) for i in range(3)])
+    got = U.cqt_batch(torch.from_numpy(waves).to(DEV))
+    T = 1 + waves.shape[1] // 256
+    assert got.shape == (3, 2, T, 84)
+    for i in range(3):
+        ref = CO.get_cqt(waves[i])
+        assert ref.shape == (2, T, 84)
+        assert float((got[i].cpu() - torch.from_numpy(ref)).abs().max()) < 2e-5 * float(np.abs(ref).max())
+    one = U.get_CQT(torch.from_numpy(waves[1:2]))                   # (1, n) host tensor, as load_audio's callers pass it
+    assert one.shape == (2, T, 84) and torch.equal(one, got[1])
+    with pytest.raises(ValueError):
+        U.get_CQT(torch.zeros(2, 4096))                             # stereo: the reference averages before the CQT
+    with pytest.raises(ValueError):
+        U.cqt_batch(torch.zeros(1, 4096, device=DEV), hop_length=96)  # librosa: hop must be a multiple of 2^6
+
+
+def test_cqt_known_answer_and_reference_shape():
+    """A unit cosine at bin k's centre frequency peaks in bin k at sqrt(length_k)/2 (librosa scale=True, norm=1); the
+    reference's own test pins the 10 s shape (2, 862, 84) (test_correctness.ipynb cell 3)."""
+    from ast_amd import utilityFunctions as U
+    sr = 22050
+    t = torch.arange(10 * sr, dtype=torch.float64) / sr
+    freqs = 32.70319566257483 * 2.0 ** (np.arange(84) / 12)
+    alpha = (2.0 ** (2 / 12) - 1) / (2.0 ** (2 / 12) + 1)
+    for k in (3, 40, 83):
+        c = U.get_CQT(torch.cos(2 * math.pi * freqs[k] * t).float()[None])
+        assert c.shape == (2, 862, 84)
+        mag = torch.sqrt(c[0, 431] ** 2 + c[1, 431] ** 2).cpu().numpy()
+        assert mag.argmax() == k and abs(mag[k] / (math.sqrt(sr / (alpha * freqs[k])) / 2) - 1) < 2e-3
+
+
+def test_load_audio_and_resample_match_oracle(tmp_path):
+    """load_audio (utilityFunctions.py:105-122): PCM decode scaling, pad/cut at the FILE's rate, torchaudio's
+    sinc_interp_hann resample, stereo mean -- against the oracle's restatement (torchaudio absent: unpinned)."""
+    from ast_amd import utilityFunctions as U
+    from oracle import cqt_oracle as CO
+    rng = np.random.default_rng(11)
+    for sr, ch, width, secs, cut in ((44100, 2, 2, 0.5, 1), (48000, 1, 3, 0.3, 0.2), (22050, 2, 2, 0.25, 1)):
+        n = int(sr * secs)
+        tt = np.arange(n) / sr
+        data = np.stack([0.4 * np.sin(2 * np.pi * (220 * (c + 1)) * tt) + 0.05 * rng.standard_normal(n) for c in range(ch)])
+        q = _write_wav(tmp_path / "a.wav", data, sr, width)
+        w, out_sr = U.load_audio(str(tmp_path / "a.wav"), cut_time_seconds=cut)
+        cutn = int(cut * sr)
+        ref = np.zeros((ch, cutn)); ref[:, :min(n, cutn)] = q[:, :cutn]
+        ref = np.stack([CO.sinc_resample(r, sr, 22050) for r in ref]).mean(axis=0, keepdims=True)
+        assert out_sr == 22050 and w.is_cuda and w.shape == ref.shape == (1, int(math.ceil(22050 * cutn / sr)))
+        assert float((w.cpu().double() - torch.from_numpy(ref)).abs().max()) < 2e-6
+    with pytest.raises(ValueError):
+        U.resample(torch.zeros(1, 8, device=DEV), 0, 22050)
+
+
+def test_dataset_items_with_device_cqt(tmp_path):
+    """DualInstrumentDataset end to end with nothing injected: WAV -> load_audio -> STFT + CQT -> per-instrument z-score ->
+    concat -> overlap windows -> collate (dataloader.py:94-147), against the oracle pipeline, and the Trainer's fused
+    front end (stft_sections + cqt_sections) against both."""
+    from ast_amd import dataloader as DL
+    from ast_amd import utilityFunctions as U
+    from oracle import cqt_oracle as CO
+    os.makedirs(tmp_path / "train_set_stats")
+    rng = np.random.default_rng(2)
+    stats = {}
+    for which in ("piano", "violin"):
+        stats[which] = {"stft_mean": rng.normal(0, 0.3, (2, 513)), "stft_std": rng.uniform(0.5, 2, (2, 513)),
+                        "cqt_mean": rng.normal(0, 0.1, (2, 84)), "cqt_std": rng.uniform(0.5, 2, (2, 84))}
+        np.savez(tmp_path / "train_set_stats" / f"stats_stft_cqt_{which}.npz", **stats[which])
+    waves = {}
+    for d, kind in (("p", "piano"), ("v", "violin")):
+        os.makedirs(tmp_path / d)
+        for i in range(4):                                  # a batch of 4 draws 4 items and keeps the first 2 (dataloader.py:133-142)
+            w = FO.synth_waveform(i, kind, seconds=4.0).reshape(1, -1)
+            waves[(kind, i)] = _write_wav(tmp_path / d / f"{i}.wav", 0.5 * w / np.abs(w).max(), 22050)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)                                      # the reference reads train_set_stats/ relative to the cwd
+    try:
+        dl = DL.get_dataloader(str(tmp_path / "p"), str(tmp_path / "v"), batch_size=4, shuffle=False)
+        dl.dataset._load_audio = lambda path: U.load_audio(path, cut_time_seconds=4)
+        x, labels = next(iter(dl))
+    finally:
+        os.chdir(cwd)
+    assert x.shape == (4, 2, 2, 287, 597) and labels.tolist() == [0, 0, 1, 1]
+    order = [("piano", 0), ("piano", 1), ("violin", 0), ("violin", 1)]
+    for b, (kind, i) in enumerate(order):
+        w = waves[(kind, i)][0]
+        st = stats[kind]
+        spec = np.concatenate([FO.normalize(FO.stft(w.astype(np.float32)[None]), st["stft_mean"], st["stft_std"]),
+                               FO.normalize(CO.get_cqt(w), st["cqt_mean"], st["cqt_std"])], axis=2)
+        ref = torch.from_numpy(FO.overlap_windows(spec).astype(np.float32))
+        assert rel_err(x[b, ..., :513], ref[..., :513]) < 1e-4
+        assert float((x[b, ..., 513:].cpu() - ref[..., 513:]).abs().max()) < 1e-4 * float(ref[..., 513:].abs().max())
+    # fused front end on the same (decoded) waveforms, per instrument statistics
+    for kind, rows in (("piano", slice(0, 2)), ("violin", slice(2, 4))):
+        wv = torch.from_numpy(np.stack([waves[(kind, i)][0] for i in range(2)]).astype(np.float32)).to(DEV)
+        st = {k: torch.from_numpy(v.astype(np.float32)).to(DEV) for k, v in stats[kind].items()}
+        xf = torch.zeros(2, 2, 2, 287, 597, device=DEV)
+        U.stft_sections(wv, st["stft_mean"], st["stft_std"], n_sections=2, F_total=597, out=xf)
+        U.cqt_sections(wv, xf, st["cqt_mean"], st["cqt_std"])
+        assert rel_err(xf, x[rows]) < 1e-5
 
 
 def test_checkpoint_layout_and_stft_stats(tmp_path):

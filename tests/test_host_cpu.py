@@ -83,3 +83,59 @@ def test_section_bookkeeping():
         assert U.section_starts(T) == FO.section_starts(T)
     with pytest.raises(ValueError):
         U.concat_stft_cqt(torch.zeros(2, 5, 3), torch.zeros(2, 6, 3))
+
+
+def test_cqt_oracle_known_answers_and_reference_shape():
+    """get_CQT (utilityFunctions.py:39-60) has no golden vector (librosa absent, parity unpinned); what can be pinned
+    is librosa's documented behaviour: a unit cosine at bin k's centre frequency peaks in bin k with magnitude
+    sqrt(length_k)/2 (scale=True, norm=1), and the reference's own test pins the shape (2, 862, 84) for 10 s."""
+    import numpy as np
+    from oracle import cqt_oracle as CO
+    sr = 22050
+    freqs = 32.70319566257483 * 2.0 ** (np.arange(84) / 12)
+    lengths, cutoff = CO.wavelet_lengths(freqs, sr, 12)
+    assert cutoff < sr / 2
+    t = np.arange(2 * sr) / sr
+    for k in (7, 43, 81):
+        mag = np.abs(CO.cqt(np.cos(2 * np.pi * freqs[k] * t)))[:, 86]
+        assert mag.argmax() == k
+        assert abs(mag[k] / (np.sqrt(lengths[k]) / 2) - 1) < 2e-3
+    out = CO.get_cqt(np.zeros((1, 10 * sr), dtype=np.float32))
+    assert out.shape == (2, 862, 84) and out.dtype == np.float32        # test_correctness.ipynb cell 3
+    assert CO.get_cqt(np.zeros(4 * sr, dtype=np.float32)).shape == (2, 345, 84)
+    # the stand-in decimator: unit DC gain, > 110 dB down from the new Nyquist on
+    h = CO.halfband()
+    H = np.abs(np.fft.rfft(h, 1 << 15))
+    f = np.arange(len(H)) / (1 << 15)
+    assert abs(h.sum() - 1) < 1e-12 and H[f >= 0.25].max() < 10 ** (-110 / 20) and abs(H[f <= 0.913 * 0.25] - 1).max() < 1e-4
+
+
+def test_cqt_plan_folds_librosa_steps_exactly():
+    """The product's per-octave correlation kernels (ast_amd/cqt.py: sparsified wavelet FFT folded with the rectangular
+    STFT) reproduce the oracle's step-by-step librosa pipeline to rounding, and its resampler bank reproduces
+    torchaudio's kernel formula as the oracle applies it."""
+    import numpy as np
+    from ast_amd import cqt as C
+    from oracle import cqt_oracle as CO
+    from oracle import frontend_oracle as FO
+    p = C._plan(22050.0, 84, 256)
+    assert p["nfft"] == 256 and [(lo, nb, h) for lo, nb, _, h, _ in p["octaves"]] == [(72 - 12 * o, 12, 256 >> o) for o in range(7)]
+    y = FO.synth_waveform(1, "violin", seconds=1.0).reshape(-1).astype(np.float64)
+    ref = CO.cqt(y)
+    T, out, yy = 1 + len(y) // 256, np.zeros_like(ref), y
+    taps = p["taps"]
+    c = (len(taps) - 1) // 2
+    for i, (lo, nb, rows, hop, sc) in enumerate(p["octaves"]):
+        yp = np.pad(yy, (128, 128 + hop))
+        frames = np.stack([yp[t * hop:t * hop + 256] for t in range(T)])
+        out[lo:lo + nb] = (p["W"][rows] @ frames.T) * sc[:, None]
+        ypad = np.pad(yy, (c, c + 2))
+        yy = np.array([np.dot(taps, ypad[2 * j:2 * j + len(taps)]) for j in range((len(yy) + 1) // 2)]) * np.sqrt(2)
+    assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-12
+    # resampler bank: 48 kHz -> 22.05 kHz is 320 -> 147
+    kern, width = C._sinc_bank(320, 147)
+    x = np.random.default_rng(3).standard_normal(3000)
+    refr = CO.sinc_resample(x, 48000, 22050)
+    xp = np.pad(x, (width, width + 320 + kern.shape[1]))
+    got = np.array([np.dot(kern[j % 147].astype(np.float64), xp[(j // 147) * 320:(j // 147) * 320 + kern.shape[1]]) for j in range(len(refr))])
+    assert np.abs(got - refr).max() < 1e-6 and len(refr) == int(np.ceil(147 * 3000 / 320))
