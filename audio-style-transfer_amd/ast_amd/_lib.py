@@ -102,7 +102,7 @@ _SIGS = {
     "ast_adam": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp, f32, vp], i32),
     "ast_counter_incr": ([vp, vp], i32),
     "ast_stft_sections": ([vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp], i32),
-    "ast_cqt_octave": ([vp, i32, i32, C.c_long, vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, vp], i32),
+    "ast_cqt_octaves": ([vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, vp], i32),
     "ast_cqt_sections": ([vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "ast_resample_poly": ([vp, i32, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp], i32),
 }

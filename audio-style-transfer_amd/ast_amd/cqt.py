@@ -17,6 +17,7 @@ are a constant table (like FFT twiddles), built once in float64 on the host.
 """
 from __future__ import annotations
 
+import ctypes
 import functools
 import math
 import wave as _wave
@@ -95,8 +96,11 @@ def _device_plan(sr, n_bins, hop, device):
     p = _plan(float(sr), int(n_bins), int(hop))
     dev = torch.device(device)
     f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    oc = p["octaves"]
     return {"nfft": p["nfft"], "w_re": f32(p["W"].real), "w_im": f32(p["W"].imag), "taps": f32(p["taps"][None, :]),
-            "ntaps": len(p["taps"]), "octaves": [(lo, nb, rows.start, h, f32(sc)) for lo, nb, rows, h, sc in p["octaves"]]}
+            "ntaps": len(p["taps"]), "octaves": oc, "los": [o[0] for o in oc], "nfs": [o[1] for o in oc],
+            "row0s": [o[2].start for o in oc], "hops": [o[3] for o in oc],
+            "scale": f32(np.concatenate([o[4] for o in reversed(oc)]))}               # by bin, low to high
 
 
 def resample_poly(x: torch.Tensor, kern: torch.Tensor, orig: int, new: int, width: int, m: int, gain: float = 1.0):
@@ -121,15 +125,17 @@ def cqt_batch(waves: torch.Tensor, sample_rate=22050, n_bins=84, hop_length=256,
     elif out.shape[:3] != (B, 2, T) or not out.is_contiguous() or out.shape[3] < bin0 + n_bins:
         raise ValueError("cqt_batch: out must be contiguous (B, 2, T, >= bin0 + n_bins)")
     ld = out.shape[3]
-    y, half = waves, (p["ntaps"] - 1) // 2
-    for i, (lo, nb, row0, hop, scale) in enumerate(p["octaves"]):
-        m = y.shape[1]
-        assert 1 + m // hop >= T                                                 # librosa trims every octave to the shortest
-        check(lib().ast_cqt_octave(ptr(y), B, m, m, ptr(p["w_re"][row0:]), ptr(p["w_im"][row0:]), ptr(scale), nb, p["nfft"], hop,
-                                   ptr(out), T, ld, bin0 + lo, stream()), "ast_cqt_octave")
-        if i + 1 < len(p["octaves"]):
-            # audio.resample(orig_sr=2, target_sr=1, scale=True): ceil(m/2) samples, times sqrt(2)
-            y = resample_poly(y, p["taps"], 2, 1, half, (m + 1) // 2, math.sqrt(2.0))
+    ys, half = [waves], (p["ntaps"] - 1) // 2
+    for _ in range(len(p["octaves"]) - 1):
+        # audio.resample(orig_sr=2, target_sr=1, scale=True): ceil(m/2) samples, times sqrt(2)
+        m = ys[-1].shape[1]
+        ys.append(resample_poly(ys[-1], p["taps"], 2, 1, half, (m + 1) // 2, math.sqrt(2.0)))
+    no = len(ys)
+    I = ctypes.c_int * no
+    assert all(1 + y.shape[1] // h >= T for y, h in zip(ys, p["hops"]))           # librosa trims every octave to the shortest
+    check(lib().ast_cqt_octaves((ctypes.c_void_p * no)(*[y.data_ptr() for y in ys]), I(*[y.shape[1] for y in ys]), I(*p["hops"]), I(*p["los"]),
+                                I(*p["nfs"]), I(*p["row0s"]), no, B, ptr(p["w_re"]), ptr(p["w_im"]), ptr(p["scale"]), p["nfft"], ptr(out), T, ld,
+                                bin0, stream()), "ast_cqt_octaves")
     return out
 
 

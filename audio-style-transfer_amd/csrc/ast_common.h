@@ -58,6 +58,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Wave-wide sum without the LDS crossbar: __shfl_xor is ds_bpermute (an LDS-pipe instruction, 6 dependent ones per
+// sum); here 4 DPP adds give every lane its 16-lane row's sum (quad swaps, then row rotations by 4 and 8) and 4
+// v_readlane pick up the four rows.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_mov<0xB1>(v);                 // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);                 // quad_perm [2,3,0,1]
+  v += dpp_mov<0x124>(v);                // row_ror:4
+  v += dpp_mov<0x128>(v);                // row_ror:8
+  const int i = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48)));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--sections", type=int, default=2, help="S=2 <=> 4 s clips")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cqt", action="store_true", help="front end runs the STFT only; the 84 CQT bins of x stay synthetic")
     ap.add_argument("--no-frontend", action="store_true", help="feed a resident model-ready x instead of running the STFT kernel each step")
     ap.add_argument("--infer", action="store_true", help="also time the autoregressive decode (BASELINE configs[3]) and add it to the JSON")
     ap.add_argument("--loss-matched", action="store_true",
@@ -192,10 +193,14 @@ def main():
     if args.no_frontend:
         x, labels = train.synthetic_batch(args.batch, args.sections, dev, seed=1000 + rank)
     else:
-        # waveforms resident in HBM; every step runs STFT + z-score + sectioning into x[..., :513] (x[..., 513:] = CQT stand-in)
+        # waveforms resident in HBM; every step runs STFT + z-score + sectioning into x[..., :513]
         waves, x, mean, std, labels = train.synthetic_waveform_batch(args.batch, clip_seconds, dev, seed=1000 + rank)
         assert x.shape[1] == args.sections
-        tr.set_frontend(waves, mean, std)
+        if args.no_cqt:
+            tr.set_frontend(waves, mean, std)
+        else:
+            # ... and the CQT of the same waveforms (get_CQT) + z-score + sectioning into x[..., 513:]
+            tr.set_frontend(waves, mean, std, torch.zeros(2, 84, device=dev), torch.full((2, 84), 0.25, device=dev))
 
     def barrier():
         if world > 1:
@@ -222,7 +227,7 @@ def main():
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": f"configs[1]: batch={args.batch} {clip_seconds:g} s clips per GPU (S={args.sections}, x=(B,S,2,287,597)), full train2 step: "
-                                  + ("" if args.no_frontend else "STFT front-end from resident waveforms (CQT bins synthetic), ")
+                                  + ("" if args.no_frontend else ("STFT front-end from resident waveforms (CQT bins synthetic), " if args.no_cqt else "STFT + CQT front-end from resident waveforms, "))
                                   + ("encoders+decoder+discriminator" if args.decoder == "new" else "encoders + SimpleDecoder_TransformerOnly (SURVEY 8(f)1, 182 M parameters) + discriminator")
                                   + ", all losses, D and G phases, grad clip, Adam",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": tr.cfg.use_graph,

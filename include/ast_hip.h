@@ -309,12 +309,15 @@ int ast_sections_overlap_avg(const float* sections, float* out, int Bc, int S, i
 int ast_stft_sections(const float* wave, int Bc, int nsamp, const float* mean, const float* std_,
                       float* x, int S, int win, int step, int F_total, void* stream);
 
-/* One octave of get_CQT (utilityFunctions.py:39-60 -> librosa.cqt): out[b][0|1][t][bin0+k] = Re|Im( scale[k] *
- * sum_i y[b][t*hop - nfft/2 + i] * (w_re + i w_im)[k][i] ), y = 0 outside [0,n) (librosa pad_mode="constant").
- * y (B rows of pitch y_stride floats), w_* (nf, nfft), out (B, 2, T, ld) f32.  The kernels w fold librosa's
- * rectangular-window STFT and its sparsified wavelet FFT basis (built on the host, ast_amd/cqt.py). */
-int ast_cqt_octave(const float* y, int B, int n, long y_stride, const float* w_re, const float* w_im, const float* scale,
-                   int nf, int nfft, int hop, float* out, int T, int ld, int bin0, void* stream);
+/* get_CQT (utilityFunctions.py:39-60 -> librosa.cqt), all octaves in one launch.  For octave o (host arrays of n_oct
+ * entries): ys[o] = device pointer to the o-times-halved signals (B rows of ns[o] floats), hops[o] its hop, los[o] its first
+ * bin, nfs[o] its bin count, row0s[o] its first kernel row.  out[b][0|1][t][bin_off+los[o]+k] = Re|Im( scale[los[o]+k] *
+ * sum_i y_o[b][t*hop_o - nfft/2 + i] * (w_re + i w_im)[row0s[o]+k][i] ), y = 0 outside the signal (pad_mode="constant").
+ * w_* (rows, nfft), scale (n_bins), out (B, 2, T, ld) f32.  The kernels w fold librosa's rectangular-window STFT and its
+ * sparsified wavelet FFT basis (built on the host, ast_amd/cqt.py). */
+int ast_cqt_octaves(const float* const* ys, const int* ns, const int* hops, const int* los, const int* nfs, const int* row0s,
+                    int n_oct, int B, const float* w_re, const float* w_im, const float* scale, int nfft, float* out, int T,
+                    int ld, int bin_off, void* stream);
 /* normalize + get_overlap_windows of the CQT planes (dataloader.py:9-18, utilityFunctions.py:240-263) into the bins behind
  * the STFT's: x[b][s][c][w][bin0+k] = (cqt[b][c][s*step+w][k] - mean[c][k]) / (std[c][k] + 1e-8), 0 past frame T-1.
  * cqt (Bc,2,T,nb), x (Bc,S,2,win,F_total) f32.  The CQT twin of ast_stft_sections. */
