@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libast_hip.so")
+LIB_PATH = os.environ.get("AST_HIP_LIB") or os.path.join(_HERE, "libast_hip.so")   # AST_HIP_LIB: same-box A/B of two builds (tools/ab.sh)
 
 F32, BF16 = 0, 1
 MAX_TAPS = 9

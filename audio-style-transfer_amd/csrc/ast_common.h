@@ -53,11 +53,6 @@ template <> struct U8<bf16_t> {
   }
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 // Wave-wide sum without the LDS crossbar: __shfl_xor is ds_bpermute (an LDS-pipe instruction, 6 dependent ones per
 // sum); here 4 DPP adds give every lane its 16-lane row's sum (quad swaps, then row rotations by 4 and 8) and 4
 // v_readlane pick up the four rows.  The result is wave-uniform.
@@ -74,6 +69,15 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16))) +
          (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48)));
 }
+#ifdef AST_WAVE_SUM_SHFL
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+#else
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
+#endif
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
