@@ -66,7 +66,7 @@ def cpu_baseline(sample_B=2, S=2, steps=2):
         print(f"[cpu_baseline] step {it}: {time.perf_counter() - t0:.2f} s", file=sys.stderr, flush=True)
     t = sorted(times)[len(times) // 2]
     return {"value": sample_B * CLIP_SECONDS / t, "unit": "audio-seconds/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fp32 step (D+G phases, clip, Adam), B={sample_B} S={S}, median of {steps} steps after 1 warm-up, {t:.2f} s/step"}
+            "sample": f"oracle fp32 step (D+G phases, clip, Adam; STFT/CQT front end NOT included, the GPU step includes it), B={sample_B} S={S}, median of {steps} steps after 1 warm-up, {t:.2f} s/step"}
 
 
 def kernel_roofline(trainer, x, labels, dtype_name):
