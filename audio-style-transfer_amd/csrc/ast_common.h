@@ -60,11 +60,16 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
-__device__ __forceinline__ float wave_sum_dpp(float v) {
+// sum over each aligned group of 16 lanes (a DPP row); every lane of the row gets it
+__device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<0xB1>(v);                 // quad_perm [1,0,3,2]
   v += dpp_mov<0x4E>(v);                 // quad_perm [2,3,0,1]
   v += dpp_mov<0x124>(v);                // row_ror:4
   v += dpp_mov<0x128>(v);                // row_ror:8
+  return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = row16_sum(v);
   const int i = __builtin_bit_cast(int, v);
   return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16))) +
          (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48)));

@@ -397,10 +397,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ s
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float a = st1[i][r], b = st2[i][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-        st1[i][r] = a; st2[i][r] = b;
+        st1[i][r] = row16_sum(st1[i][r]);                        // DPP, not ds_bpermute: the LDS pipe is this kernel's bound
+        st2[i][r] = row16_sum(st2[i][r]);
       }
 #pragma unroll
     for (int i0 = 0; i0 < TN; i0 += 2) {
