@@ -11,18 +11,18 @@ constexpr float PI_F = 3.14159265358979323846f;
 // ---- compute_comprehensive_loss (new_decoder.py:348-420) ---------------------------
 // thread = one (b, t, f) complex bin, loops over the S sections so the section
 // differences stay in registers; t+-1 neighbours come from L1/L2.
-__global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict__ out, const float* __restrict__ tgt, int64_t tld,
+__global__ __launch_bounds__(1024) void recon_loss_kernel(const float* __restrict__ out, const float* __restrict__ tgt, int64_t tld,
                                                           int B, int S, int T, int Fq, float c_mse, float c_mag, float c_ph,
                                                           float c_tmp, float c_spc, float* __restrict__ sums, float* __restrict__ grad) {
   __shared__ float red[17];
-  const size_t total = (size_t)B * T * Fq;
+  const unsigned total = (unsigned)B * T * Fq;                  // < 2^31 (host check): 32-bit index math, no 64-bit divisions
   const size_t plane_o = (size_t)T * Fq, plane_t = (size_t)T * tld;
   float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int f = (int)(i % Fq);
-    const size_t r = i / Fq;
-    const int t = (int)(r % T);
-    const int b = (int)(r / T);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int f = (int)(i % (unsigned)Fq);
+    const unsigned r = i / (unsigned)Fq;
+    const int t = (int)(r % (unsigned)T);
+    const int b = (int)(r / (unsigned)T);
     float eprev[2] = {0.f, 0.f};     // e[s-1] at (t,f)
     for (int s = 0; s < S; ++s) {
       const size_t sec = (size_t)b * S + s;
@@ -366,8 +366,12 @@ extern "C" int ast_recon_loss(const float* out, const float* tgt, int64_t tgt_ld
   hipStream_t s = (hipStream_t)stream;
   AST_HIP(hipMemsetAsync(sums, 0, 5 * sizeof(float), s));
   const size_t total = (size_t)B * T * Fq;
-  const int grid = (int)std::min<size_t>((total + 255) / 256, 1024);   // 5 same-address atomics per block: keep the count low
-  hipLaunchKernelGGL(recon_loss_kernel, dim3(grid), dim3(256), 0, s, out, tgt, tgt_ld, B, S, T, Fq, c_mse, c_mag, c_phase, c_temporal,
+  if (total >= (1ull << 31)) AST_FAIL("ast_recon_loss: more than 2^31 bins per section");
+  // every workgroup ends in 5 same-address f32 atomics, which serialise at ~10 ns each (1024 workgroups of 256: ~50 of the
+  // kernel's 95 us; 4608: +250 us): the same 256 K threads as 256 workgroups of 1024
+  static const int max_blocks = getenv("AST_RECON_BLOCKS") ? atoi(getenv("AST_RECON_BLOCKS")) : 256;
+  const int grid = (int)std::min<size_t>((total + 1023) / 1024, (size_t)std::max(1, max_blocks));
+  hipLaunchKernelGGL(recon_loss_kernel, dim3(grid), dim3(1024), 0, s, out, tgt, tgt_ld, B, S, T, Fq, c_mse, c_mag, c_phase, c_temporal,
                      c_spectral, sums, grad);
   AST_CHECK_LAUNCH();
   return 0;
