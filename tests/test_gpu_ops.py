@@ -85,6 +85,9 @@ def sn_reference_weight(m, dim):
     (64, 128, 3, 2, 9, 19, 2),
     (128, 256, 3, 1, 5, 10, 2),
     (16, 64, 1, 2, 11, 14, 2),     # shortcut conv
+    (2, 16, 3, 1, 29, 41, 2),      # narrow layers: the LDS-free direct kernel (<= 16 output channels, K <= 12 chunks)
+    (8, 8, 3, 2, 21, 18, 3),
+    (16, 16, 1, 1, 13, 17, 2),
     (64, 1, 1, 1, 32, 16, 2),      # spatial_projection.3
     (2, 16, 3, 1, 30, 41, 1),
 ])
@@ -116,6 +119,17 @@ def test_conv2d_fwd_bwd(dtype, cin, cout, k, stride, H, W, N):
     assert rel_err(m.bias.grad, gy.sum(dim=(0, 2, 3))) < tol
     # power iteration side effects (torch spectral_norm.py:97-113)
     assert rel_err(m.weight_u, sd["weight_u"]) < 1e-4 and rel_err(m.weight_v, sd["weight_v"]) < 1e-4
+
+
+def test_direct_kernel_selected_for_narrow_layers():
+    """ast_igemm_plan reports the LDS-free kernel (kch = 0) exactly for <= 16 output channels and <= 12 K chunks."""
+    bf, f32 = ops.dcode(torch.bfloat16), ops.dcode(torch.float32)
+    g, _ = ops.gather_direct(2, 29, 41, 8, 16, 3, 1, 1)          # 9 taps x 8 channels: 9 bf16 chunks, 18 f32 chunks
+    assert ",k0B" in ops._igemm_config(g, bf) and ",k0B" not in ops._igemm_config(g, f32)
+    g, _ = ops.gather_direct(2, 29, 41, 16, 16, 1, 1, 0)
+    assert ",k0B" in ops._igemm_config(g, bf) and ",k0B" in ops._igemm_config(g, f32)
+    g, _ = ops.gather_direct(2, 29, 41, 8, 32, 3, 1, 1)
+    assert ",k0B" not in ops._igemm_config(g, bf)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
