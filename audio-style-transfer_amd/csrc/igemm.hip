@@ -84,14 +84,10 @@ struct EpiCtx {
   int HWm; float rcp_hw, rcp_w; bool accumulate, relu, stats, bstats, bn_relu;
 };
 
-// One destination pixel m: the lane owns channels co0 + i*16 .. +3 of channel tile i (col[i] = their accumulators).
-// Adds bias, accumulates the fused BatchNorm forward / backward sums of the values as stored, stores.
+// The same for a known destination pixel index `pix` (pixels of the dst tensor, not bytes).
 template <typename T, int TN>
-__device__ __forceinline__ void epi_pixel(const EpiCtx<T>& ec, const ast_gather_t& g, const f32x4 (&col)[TN], const int m, const int co0,
+__device__ __forceinline__ void epi_store(const EpiCtx<T>& ec, const ast_gather_t& g, const f32x4 (&col)[TN], const size_t pix, const int co0,
                                           float (&st1)[TN][4], float (&st2)[TN][4]) {
-  const int n = fdiv(m, ec.HWm, ec.rcp_hw), rem = m - n * ec.HWm;
-  const int hm = fdiv(rem, g.Wm, ec.rcp_w), wq = rem - hm * g.Wm;
-  const size_t pix = (size_t)(n * g.Hd + hm * g.dsh + g.doh) * g.Wd + (wq * g.dsw + g.dow);
   T* drow = ec.dst + pix * g.Cd;
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
@@ -134,6 +130,16 @@ __device__ __forceinline__ void epi_pixel(const EpiCtx<T>& ec, const ast_gather_
     }
     store4<T>(drow + co, v, ec.accumulate, ec.relu);
   }
+}
+
+// One destination pixel m: the lane owns channels co0 + i*16 .. +3 of channel tile i (col[i] = their accumulators).
+// Adds bias, accumulates the fused BatchNorm forward / backward sums of the values as stored, stores.
+template <typename T, int TN>
+__device__ __forceinline__ void epi_pixel(const EpiCtx<T>& ec, const ast_gather_t& g, const f32x4 (&col)[TN], const int m, const int co0,
+                                          float (&st1)[TN][4], float (&st2)[TN][4]) {
+  const int n = fdiv(m, ec.HWm, ec.rcp_hw), rem = m - n * ec.HWm;
+  const int hm = fdiv(rem, g.Wm, ec.rcp_w), wq = rem - hm * g.Wm;
+  epi_store<T, TN>(ec, g, col, (size_t)(n * g.Hd + hm * g.dsh + g.doh) * g.Wd + (wq * g.dsw + g.dow), co0, st1, st2);
 }
 
 // The tile's fused sums -> the slot table.  Reduce over the 16 pixels of the lane group, then spread the (tile, channel,
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(const T* __restrict__
 #pragma unroll
     for (int r = 0; r < 4; ++r) { st1[i][r] = 0.f; st2[i][r] = 0.f; }
 
-  auto load_pix = [&](int j, u32x4 (&xr)[NKS]) __attribute__((always_inline)) {
+  auto load_pix = [&](int j, u32x4 (&xr)[NKS], int& dpix) __attribute__((always_inline)) {
     const int m = bm0 + j * 16 + fr;
     const bool valid = j < jt && m < M;
     const int mm = valid ? m : 0;
@@ -530,13 +536,14 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(const T* __restrict__
     const int hs0 = valid ? hm * g.sh + g.oh : -(1 << 20);
     const int ws0 = wq * g.sw + g.ow;
     const int roff = (((n * g.Hs + (valid ? hs0 : 0)) * g.Ws + ws0) * g.Cs) * ES;
+    dpix = (n * g.Hd + hm * g.dsh + g.doh) * g.Wd + (wq * g.dsw + g.dow);   // the tile's destination pixel, decoded once
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const bool ok = (unsigned)(hs0 + tdh[ks]) < (unsigned)g.Hs && (unsigned)(ws0 + tdw[ks]) < (unsigned)g.Ws;
       xr[ks] = __builtin_amdgcn_raw_buffer_load_b128(srcR, ok ? (unsigned)(roff + sdelta[ks]) : OOB, 0, 0);
     }
   };
-  auto compute = [&](int j, const u32x4 (&xr)[NKS]) __attribute__((always_inline)) {
+  auto compute = [&](int j, const u32x4 (&xr)[NKS], const int dpix) __attribute__((always_inline)) {
     f32x4 acc[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -549,16 +556,17 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(const T* __restrict__
       }
     }
     const int m = bm0 + j * 16 + fr;
-    if (m < M) epi_pixel<T, TN>(ec, g, acc, m, bn0 + fq * 4, st1, st2);
+    if (m < M) epi_store<T, TN>(ec, g, acc, (size_t)dpix, bn0 + fq * 4, st1, st2);
   };
 
   u32x4 xa[NKS], xb[NKS];
-  load_pix(0, xa);
+  int pa, pb;
+  load_pix(0, xa, pa);
   for (int j = 0; j < jt; j += 2) {                          // uniform trip count
-    load_pix(j + 1, xb);
-    compute(j, xa);
-    load_pix(j + 2, xa);
-    if (j + 1 < jt) compute(j + 1, xb);
+    load_pix(j + 1, xb, pb);
+    compute(j, xa, pa);
+    load_pix(j + 2, xa, pa);
+    if (j + 1 < jt) compute(j + 1, xb, pb);
   }
   if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, tix, bn0, fr, fq);
 }
@@ -1071,6 +1079,7 @@ bool direct_ok(const ast_gather_t& g, const IgemmPlan& p, int dtype) {
   // 7.04 -> 6.91 ms with this rule, 7.10 with everything up to 32 channels x 36 chunks)
   static const int max_cd = getenv("AST_IGEMM_DIRECT_CD") ? atoi(getenv("AST_IGEMM_DIRECT_CD")) : 16;
   static const int max_chunks = getenv("AST_IGEMM_DIRECT_CHUNKS") ? atoi(getenv("AST_IGEMM_DIRECT_CHUNKS")) : 12;
+  if ((long)g.N * g.Hd * g.Wd >= (1L << 31)) return false;     // the kernel keeps destination pixel indices in 32 bits
   return enabled && g.Cd <= std::min(max_cd, 32) && nchunks <= std::min(max_chunks, 12) && p.nsplit == 1 && p.kgroups == 1 &&
          !getenv("AST_IGEMM_FORCE");
 }

@@ -68,6 +68,8 @@ int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst,
  * so ast_norm_bwd_sums need not run (reduce with ast_norm_bwd_finalize(N = 64, count = pixels)).  Plans without split-K. */
 int ast_igemm_bn(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t* g, int dtype, int flags,
                  float* ws, long ws_floats, const void* bn_x, const float* bn_scale, const float* bn_shift, void* stream);
+/* Narrow layers (Cd <= 16, ntaps*Cs <= 12 sixteen-byte chunks) run an LDS-free kernel: each lane's gather load is its
+ * MFMA fragment, the weights stay in registers (ast_igemm_plan reports it as kch = 0).  Same results, same flags. */
 /* f32 workspace (floats) ast_igemm needs for this geometry: >0 when the launch is split over K
  * (under-filled grids of the deep, small-M layers), 0 otherwise, <0 on a bad geometry. */
 long ast_igemm_ws_floats(const ast_gather_t* g, int dtype);
