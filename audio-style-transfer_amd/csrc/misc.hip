@@ -306,14 +306,14 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restric
   }
 }
 
-// Y[o][d] = sum_i A[o][i] X[i][d] for a small dense coefficient matrix A (<= 64 x 64): per-class means of embeddings
+// Y[o][d] = sum_i A[o][i] X[i][d] for a small dense coefficient matrix A (R_in <= 8192): per-class means of embeddings
 // (style_encoder.py:243-253), the per-row class-prototype gather (new_decoder.py:214-223 callers), means over the
 // section axis (losses.py:88, 142) and their backward passes (A transposed).  One workgroup per output row.
 __global__ __launch_bounds__(256) void rowmix_kernel(const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ Y,
                                                      int R_in, int D) {
   const int o = blockIdx.x;
-  __shared__ float a[64];
-  if ((int)threadIdx.x < R_in) a[threadIdx.x] = A[(size_t)o * R_in + threadIdx.x];
+  extern __shared__ float a[];                                  // R_in coefficients of this output row
+  for (int i = threadIdx.x; i < R_in; i += 256) a[i] = A[(size_t)o * R_in + i];
   __syncthreads();
   for (int d = threadIdx.x; d < D; d += 256) {
     float acc = 0.f;
@@ -484,8 +484,8 @@ extern "C" int ast_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, 
 }
 
 extern "C" int ast_rowmix(const float* A, const float* X, float* Y, int R_out, int R_in, int D, void* stream) {
-  if (!A || !X || !Y || R_out < 1 || R_in < 1 || R_in > 64 || D < 1) AST_FAIL("ast_rowmix: bad args R_out=%d R_in=%d D=%d", R_out, R_in, D);
-  hipLaunchKernelGGL(rowmix_kernel, dim3(R_out), dim3(256), 0, (hipStream_t)stream, A, X, Y, R_in, D);
+  if (!A || !X || !Y || R_out < 1 || R_in < 1 || R_in > 8192 || D < 1) AST_FAIL("ast_rowmix: bad args R_out=%d R_in=%d D=%d", R_out, R_in, D);
+  hipLaunchKernelGGL(rowmix_kernel, dim3(R_out), dim3(256), R_in * sizeof(float), (hipStream_t)stream, A, X, Y, R_in, D);
   AST_CHECK_LAUNCH();
   return 0;
 }

@@ -219,7 +219,7 @@ int ast_add_drop_ln_bwd(const float* dy, const float* ds_ext, const float* s, co
                         const float* rstd, const float* mask, float* dx, float* dsub, float* dgamma, float* dbeta, int rows,
                         int D, void* stream);
 
-/* Y[R_out][D] = A[R_out][R_in] X[R_in][D], A a small dense coefficient matrix (R_in <= 64): class prototypes = per-class
+/* Y[R_out][D] = A[R_out][R_in] X[R_in][D], A a small dense coefficient matrix (R_in <= 8192): class prototypes = per-class
  * means of style embeddings (style_encoder.py:243-253), per-row prototype gather, means over the section axis
  * (losses.py:88,142); the backward pass is the same call with A transposed. */
 int ast_rowmix(const float* A, const float* X, float* Y, int R_out, int R_in, int D, void* stream);

@@ -121,6 +121,23 @@ def test_conv2d_fwd_bwd(dtype, cin, cout, k, stride, H, W, N):
     assert rel_err(m.weight_u, sd["weight_u"]) < 1e-4 and rel_err(m.weight_v, sd["weight_v"]) < 1e-4
 
 
+@pytest.mark.parametrize("R_out,R_in", [(2, 8), (16, 32), (64, 128), (3, 300)])
+def test_rowmix_fwd_bwd(R_out, R_in):
+    """ast_rowmix (class prototypes / prototype gather / section means, style_encoder.py:243-253, losses.py:88,142) for
+    any row count -- a per-GPU batch of 64 two-section clips mixes 128 rows."""
+    torch.manual_seed(31)
+    A = torch.randn(R_out, R_in) * (torch.rand(R_out, R_in) > 0.5)
+    x = torch.randn(R_in, 256)
+    xr = x.clone().requires_grad_(True)
+    yr = A @ xr
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.RowMixFn.apply(xd, A.to(DEV), A.t().contiguous().to(DEV))
+    y.backward(gy.to(DEV))
+    assert rel_err(y, yr) < 1e-5 and rel_err(xd.grad, xr.grad) < 1e-5
+
+
 def test_direct_kernel_selected_for_narrow_layers():
     """ast_igemm_plan reports the LDS-free kernel (kch = 0) exactly for <= 16 output channels and <= 12 K chunks."""
     bf, f32 = ops.dcode(torch.bfloat16), ops.dcode(torch.float32)
