@@ -68,6 +68,24 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<0x128>(v);                // row_ror:8
   return v;
 }
+// Sixteen values per lane -> lane l of every 16-lane row gets the row-wide sum of value l (a transposed reduction:
+// 8 + 4 + 2 + 1 exchange steps instead of 16 x 4).  Partners are l^1, l^2 (quad permutes), l^4 (row rotations by 4 and
+// 12, selected by bit 2), l^8 (rotation by 8).
+__device__ __forceinline__ float row16_transpose_sum(const float (&v)[16], const int l) {
+  float w[8], x[4], y[2];
+  const bool b0 = l & 1, b1 = l & 2, b2 = l & 4, b3 = l & 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = (b0 ? v[2 * k + 1] : v[2 * k]) + dpp_mov<0xB1>(b0 ? v[2 * k] : v[2 * k + 1]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x[k] = (b1 ? w[2 * k + 1] : w[2 * k]) + dpp_mov<0x4E>(b1 ? w[2 * k] : w[2 * k + 1]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float send = b2 ? x[2 * k] : x[2 * k + 1];
+    const float lo = dpp_mov<0x124>(send), hi = dpp_mov<0x12C>(send);      // row_ror:4 = from lane l-4, row_ror:12 = from lane l+4
+    y[k] = (b2 ? x[2 * k + 1] : x[2 * k]) + (b2 ? lo : hi);
+  }
+  return (b3 ? y[1] : y[0]) + dpp_mov<0x128>(b3 ? y[0] : y[1]);
+}
 __device__ __forceinline__ float wave_sum_dpp(float v) {
   v = row16_sum(v);
   const int i = __builtin_bit_cast(int, v);

@@ -152,24 +152,19 @@ __device__ __forceinline__ void epi_flush(float* ws, const bool bstats, const in
   const int KS = bstats ? 3 : 2;                               // floats per channel in the slot table
   float* slot = ws + (size_t)(tix & 63) * Cd * KS;
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      st1[i][r] = row16_sum(st1[i][r]);                        // DPP, not ds_bpermute: the LDS pipe is this kernel's bound
-      st2[i][r] = row16_sum(st2[i][r]);
-    }
-#pragma unroll
   for (int i0 = 0; i0 < TN; i0 += 2) {
-    float val = 0.f;
+    // value q = ii*8 + r*2 + which (which: 0 = st1, 1 = st2) ends, summed over the 16 pixels, in lane fr = q
+    float v[16];
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (i0 + ii < TN) {
-          if (fr == ii * 8 + r * 2) val = st1[i0 + ii][r];
-          if (fr == ii * 8 + r * 2 + 1) val = st2[i0 + ii][r];
-        }
+        constexpr int NT = TN;                                  // an odd TN leaves the second half of the last pair empty
+        const int it = i0 + ii < NT ? i0 + ii : 0;
+        v[ii * 8 + r * 2] = i0 + ii < NT ? st1[it][r] : 0.f;
+        v[ii * 8 + r * 2 + 1] = i0 + ii < NT ? st2[it][r] : 0.f;
       }
+    const float val = row16_transpose_sum(v, fr);
     const int ii = fr >> 3, r = (fr >> 1) & 3, which = fr & 1;
     const int co = cbase + (i0 + ii) * 16 + fq * 4 + r;
     if (i0 + ii < TN && co < Cd) unsafeAtomicAdd(slot + (size_t)co * KS + which, val);
