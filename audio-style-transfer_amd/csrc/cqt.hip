@@ -59,39 +59,61 @@ __global__ __launch_bounds__(256) void cqt_octave_kernel(const CqtOctaves oc, co
     span[i] = (s >= 0 && s < n) ? yb[s] : 0.0f;
   }
   __syncthreads();
+  if constexpr (NPL > 0) {
+    // 8 frames x 3 filters x (re, im) = 48 per-lane partial sums.  Three transposed reductions of 16 values each
+    // (row16_transpose_sum: lane l of a 16-lane row ends with the row's sum of value l), two cross-row exchanges, and
+    // lanes 0..15 store one result each -- instead of 48 separate wave sums (which made the kernel VALU-issue bound).
+    static_assert(AST_CQT_FR * 6 == 48, "three groups of sixteen");
+    float part[AST_CQT_FR * 6];
 #pragma unroll
-  for (int fr = 0; fr < (NPL > 0 ? AST_CQT_FR : nfr); ++fr) {           // unrolled: the frames' reductions interleave
-    if (fr >= nfr) break;
-    const float* frame = span + fr * hop;
-    const int t = t0 + fr;
-    float fv[NR];
-    if (NPL > 0) {
+    for (int fr = 0; fr < AST_CQT_FR; ++fr) {
+      const float* frame = span + fr * hop;                            // frames past nfr read stale LDS: never stored
+      float fv[NR];
 #pragma unroll
       for (int i = 0; i < NR; ++i) fv[i] = frame[lane + 64 * i];
-    }
 #pragma unroll
-    for (int f = 0; f < (NPL > 0 ? 3 : 1); ++f) {
-      for (int k = wave + 4 * f; k < nf; k += (NPL > 0 ? nf : 4)) {        // NPL > 0: exactly one filter per f
+      for (int f = 0; f < 3; ++f) {
         float re = 0.0f, im = 0.0f;
-        if (NPL > 0) {
 #pragma unroll
-          for (int i = 0; i < NR; ++i) {
-            re = __builtin_fmaf(fv[i], wr[f][i], re);
-            im = __builtin_fmaf(fv[i], wi[f][i], im);
-          }
-        } else {
-          const float* pr = w_re + (size_t)k * nfft;
-          const float* pi = w_im + (size_t)k * nfft;
-          for (int i = lane; i < nfft; i += 64) {
-            const float v = frame[i];
-            re = __builtin_fmaf(v, pr[i], re);
-            im = __builtin_fmaf(v, pi[i], im);
-          }
+        for (int i = 0; i < NR; ++i) {
+          re = __builtin_fmaf(fv[i], wr[f][i], re);
+          im = __builtin_fmaf(fv[i], wi[f][i], im);
         }
-        re = wave_sum_dpp(re);                                           // 12 ds_bpermute per (frame, filter) made this
-        im = wave_sum_dpp(im);                                           // kernel LDS-issue bound: 42 us -> see DESIGN
+        part[fr * 6 + f * 2] = re;
+        part[fr * 6 + f * 2 + 1] = im;
+      }
+    }
+    const int l = lane & 15;
+#pragma unroll
+    for (int grp = 0; grp < 3; ++grp) {
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = part[grp * 16 + q];
+      float val = row16_transpose_sum(v, l);
+      val += __shfl_xor(val, 16);
+      val += __shfl_xor(val, 32);
+      const int q = grp * 16 + l, fr = q / 6, f = (q - fr * 6) >> 1, c = q & 1;
+      const int k = wave + 4 * f, t = t0 + fr;
+      if (lane < 16 && fr < nfr && k < nf)
+        out[((size_t)b * 2 * T + (size_t)c * T + t) * ld + bin0 + k] = val * scale[k];   // (B, 2, T, ld): real plane, then imaginary
+    }
+  } else {
+    for (int fr = 0; fr < nfr; ++fr) {
+      const float* frame = span + fr * hop;
+      const int t = t0 + fr;
+      for (int k = wave; k < nf; k += 4) {
+        float re = 0.0f, im = 0.0f;
+        const float* pr = w_re + (size_t)k * nfft;
+        const float* pi = w_im + (size_t)k * nfft;
+        for (int i = lane; i < nfft; i += 64) {
+          const float v = frame[i];
+          re = __builtin_fmaf(v, pr[i], re);
+          im = __builtin_fmaf(v, pi[i], im);
+        }
+        re = wave_sum_dpp(re);
+        im = wave_sum_dpp(im);
         if (lane == 0) {
-          float* o = out + ((size_t)b * 2 * T + t) * ld + bin0 + k;    // (B, 2, T, ld): real plane, then imaginary plane
+          float* o = out + ((size_t)b * 2 * T + t) * ld + bin0 + k;
           o[0] = re * scale[k];
           o[(size_t)T * ld] = im * scale[k];
         }
