@@ -462,8 +462,8 @@ class Trainer:
 
 def synthetic_waveform_batch(B, seconds, device, seed=1000, sr=22050):
     """Synthetic clips for the front-end-inclusive step: B mono waveforms (first half piano-like decaying
-    partials, second half violin-like sustained harmonics with vibrato), RMS 0.07, plus N(0,1) stand-ins for
-    the 84 z-scored CQT bins (CQT is librosa arithmetic: parity-unpinned, not built) and per-bin statistics."""
+    partials, second half violin-like sustained harmonics with vibrato), RMS 0.07, plus N(0,1) initial values for
+    the 84 z-scored CQT bins (overwritten by the device CQT when the front end is given cqt statistics) and per-bin statistics."""
     g = torch.Generator().manual_seed(seed)
     n = int(round(seconds * sr))
     t = torch.arange(n, dtype=torch.float32) / sr
@@ -483,7 +483,7 @@ def synthetic_waveform_batch(B, seconds, device, seed=1000, sr=22050):
     T = 1 + n // 256
     from .utilityFunctions import section_starts
     S = len(section_starts(T))
-    x = torch.randn((B, S, 2, 287, 597), generator=g, dtype=torch.float32).to(device)     # bins 513.. = CQT stand-in
+    x = torch.randn((B, S, 2, 287, 597), generator=g, dtype=torch.float32).to(device)     # bins 513.. are replaced by get_CQT when Trainer.set_frontend gets cqt stats
     mean = (0.01 * torch.randn(2, 513, generator=g)).to(device)
     std = (0.5 + torch.rand(2, 513, generator=g)).to(device)
     labels = torch.cat([torch.zeros(B // 2, dtype=torch.long), torch.ones(B - B // 2, dtype=torch.long)])
