@@ -9,10 +9,22 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   float q = 0.f;
   const size_t n4 = n / 4;
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+  // four 16-byte loads in flight per thread (the straight loop waited for each: 3 TB/s on 124 MB)
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float q1 = 0.f, q2 = 0.f, q3 = 0.f;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const f32x4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+    q += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+    q1 += b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+    q2 += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3];
+    q3 += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+  }
+  for (; i < n4; i += stride) {
     const f32x4 v = x4[i];
     q += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
   }
+  q += (q1 + q2) + q3;
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[n4 * 4 + threadIdx.x]; q += v * v; }
   q = block_sum(q, red);
   if (threadIdx.x == 0) unsafeAtomicAdd(out, q);
@@ -41,7 +53,10 @@ extern "C" int ast_sumsq(const float* x, int64_t n, float* out, void* stream) {
   if (!x || !out || n < 0) AST_FAIL("ast_sumsq: bad args");
   if (n == 0) return 0;
   if (((uintptr_t)x) & 15) AST_FAIL("ast_sumsq: x must be 16-byte aligned");
-  const int grid = (int)std::min<size_t>(((size_t)n / 4 + 255) / 256 + 1, 2048);
+  // one same-address f32 atomic per workgroup, ~11 ns each once they queue up: 2048 workgroups 38 us, 1024 28 us,
+  // 512 23 us, 256 21 us (5.9 TB/s) for the 31 M-parameter gradient (tools/sumsq_time.py)
+  static const int max_blocks = getenv("AST_SUMSQ_BLOCKS") ? atoi(getenv("AST_SUMSQ_BLOCKS")) : 256;
+  const int grid = (int)std::min<size_t>(((size_t)n / 4 + 255) / 256 + 1, (size_t)std::max(1, max_blocks));
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, out);
   AST_CHECK_LAUNCH();
   return 0;
