@@ -270,20 +270,36 @@ __global__ void colsum_acc_kernel(const T* __restrict__ x, size_t rows, int C, i
   for (size_t r = r0; r < r1; ++r) a += (float)x[r * C + c];
   unsafeAtomicAdd(out + c, a);
 }
-// small C (<= 64): thread = (row lane, column); LDS reduce over row lanes
+// small C (<= 64, a multiple of 8): the tensor is read as a flat stream of 8-element chunks, four 16-byte loads in flight
+// per thread; a thread always meets the same column octet (the grid stride is a multiple of C/8), keeps 8 column sums,
+// and the workgroup combines them through LDS before ONE atomic per column.  (The first version read one 2-byte
+// element per thread per step: 31 us for the 67 MB of a 2 M-pixel x 16-channel bias gradient.)
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__ x, size_t rows, int C, int Creal, float* __restrict__ out,
-                                                            size_t rows_per_blk) {
-  __shared__ float red[256];
-  const int c = threadIdx.x % C, rl = threadIdx.x / C, RL = 256 / C;
-  const size_t r0 = (size_t)blockIdx.x * rows_per_blk, r1 = r0 + rows_per_blk < rows ? r0 + rows_per_blk : rows;
-  float a = 0.f;
-  if (rl < RL) for (size_t r = r0 + rl; r < r1; r += RL) a += (float)x[r * C + c];
-  red[threadIdx.x] = a;
+__global__ __launch_bounds__(256) void colsum_small_kernel(const T* __restrict__ x, size_t n8, int C, int Creal, float* __restrict__ out) {
+  __shared__ float red[256][9];
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n8; i += 4 * stride) {
+    float a[8], b[8], c[8], d[8];
+    U8<T>::load(x + i * 8, a); U8<T>::load(x + (i + stride) * 8, b);
+    U8<T>::load(x + (i + 2 * stride) * 8, c); U8<T>::load(x + (i + 3 * stride) * 8, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += (a[e] + b[e]) + (c[e] + d[e]);
+  }
+  for (; i < n8; i += stride) {
+    float a[8];
+    U8<T>::load(x + i * 8, a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += a[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
   __syncthreads();
-  if (threadIdx.x < Creal) {
+  if ((int)threadIdx.x < Creal) {
+    const int no = C >> 3, oct = threadIdx.x >> 3, e = threadIdx.x & 7;
     float t = 0.f;
-    for (int q = 0; q < RL; ++q) t += red[q * C + threadIdx.x];
+    for (int q = oct; q < 256; q += no) t += red[q][e];
     unsafeAtomicAdd(out + threadIdx.x, t);
   }
 }
@@ -458,11 +474,11 @@ extern "C" int ast_mul(const void* a, const float* mask, void* y, int64_t n, int
 extern "C" int ast_colsum_acc(const void* x, int64_t rows, int C, int Creal, float* out, int dtype, void* stream) {
   if (!x || !out || rows < 0 || C <= 0 || Creal > C) AST_FAIL("ast_colsum_acc: bad args");
   if (rows == 0) return 0;
-  if (C <= 64) {
-    const int nb = (int)std::min<size_t>(512, ((size_t)rows * C + 16383) / 16384);
-    const size_t rpb = ((size_t)rows + nb - 1) / nb;
-    AST_DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_small_kernel<T>), dim3((unsigned)(((size_t)rows + rpb - 1) / rpb)), dim3(256), 0,
-                                              (hipStream_t)stream, (const T*)x, (size_t)rows, C, Creal, out, rpb));
+  if (C <= 64 && !(C & 7) && !(C & (C - 1)) && !((uintptr_t)x & 15)) {      // 8, 16, 32, 64 channels: C/8 divides the grid stride
+    const size_t n8 = (size_t)rows * C / 8;
+    const int nb = (int)std::min<size_t>(256, (n8 + 1023) / 1024);                 // few workgroups: one atomic per column each
+    AST_DISPATCH_T(dtype, hipLaunchKernelGGL((colsum_small_kernel<T>), dim3(std::max(nb, 1)), dim3(256), 0, (hipStream_t)stream, (const T*)x, n8,
+                                              C, Creal, out));
     AST_CHECK_LAUNCH();
     return 0;
   }

@@ -138,6 +138,21 @@ def test_rowmix_fwd_bwd(R_out, R_in):
     assert rel_err(y, yr) < 1e-5 and rel_err(xd.grad, xr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C,Creal", [(5000, 8, 2), (70001, 16, 16), (333, 32, 30), (12345, 64, 64), (4097, 24, 24), (900, 128, 128)])
+def test_colsum_acc_bias_gradient(dtype, rows, C, Creal):
+    """ast_colsum_acc: bias gradients = column sums of dy (rows, C), accumulated into the gradient (nn.Conv2d / Linear
+    backward); the vector path (C in 8/16/32/64) and the general path."""
+    from ast_amd._lib import lib, check, ptr, stream
+    torch.manual_seed(41)
+    x = torch.randn(rows, C).to(dtype)
+    g0 = torch.randn(Creal)
+    g = g0.clone().to(DEV)
+    check(lib().ast_colsum_acc(ptr(x.to(DEV)), rows, C, Creal, ptr(g), ops.dcode(dtype), stream()), "ast_colsum_acc")
+    ref = g0 + x.double().sum(0)[:Creal].float()
+    assert rel_err(g, ref) < 2e-5
+
+
 def test_direct_kernel_selected_for_narrow_layers():
     """ast_igemm_plan reports the LDS-free kernel (kch = 0) exactly for <= 16 output channels and <= 12 K chunks."""
     bf, f32 = ops.dcode(torch.bfloat16), ops.dcode(torch.float32)
