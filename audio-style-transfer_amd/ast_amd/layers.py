@@ -51,7 +51,6 @@ class WeightBank:
 
     def _build(self, training):
         dev = self.specs[0][0].device
-        first = self._key is None or self._key[1:] != self._signature(training)[1:] or True
         descs, dts = [], []
         self.max_co = self.max_cols = self.max_packed = 1
         # packed f32 gradient staging for every conv / conv-transpose weight: ONE arena, zeroed by the
@@ -89,12 +88,15 @@ class WeightBank:
             e.weight, e.u, e.v, e.bias, e.bank = w, u, v, bias, self
             e.Co, e.Ci, e.KK, e.s_co, e.s_ci, e.w_off, e.b_off = Co, Ci, KK, s_co, s_ci, w_off, b_off
             e.Cop, e.Cip, e.dtype = pad8(Co), pad8(Ci), dt
-            e.dwp = None
+            # training-only state (gradient staging slice) is left alone by an eval build: a validation pass or an
+            # inference session between two training steps must not invalidate the training descriptors
             grad_ptr = None
-            if training and sz:
-                e.dwp = self.dw_arena[off:off + sz]
-                off += sz
-                grad_ptr = ops.acc_grad(w).data_ptr() + 4 * w_off
+            if training:
+                e.dwp = None
+                if sz:
+                    e.dwp = self.dw_arena[off:off + sz]
+                    off += sz
+                    grad_ptr = ops.acc_grad(w).data_ptr() + 4 * w_off
             descs.append(WeightDesc(w=w.data_ptr() + 4 * w_off, u=ptr(u), v=ptr(v), sigma=ptr(e.sigma), scratch=ptr(e.scratch),
                                     wf=ptr(e.wf), wb=ptr(e.wb), Co=Co, Ci=Ci, KK=KK, s_co=s_co, s_ci=s_ci, Cop=e.Cop, Cip=e.Cip,
                                     power_iter=1 if training else 0, dwp=ptr(e.dwp), grad=grad_ptr, inner=ptr(e.gtmp),
@@ -158,12 +160,24 @@ class WeightBank:
                 recs.append(LinWg(dy=dy.data_ptr(), x=x.data_ptr(), dW=gw.data_ptr() + 4 * pw.w_off, db=gb or None, M=x.shape[0],
                                   N=pw.Co, K=pw.Ci, lddy=pw.Cop, ldw=pw.s_co, p0=0, p1=0, p2=0))
                 max_tiles = max(max_tiles, ((pw.Ci + 63) // 64) * ((pw.Co + 63) // 64))
-            arr = (LinWg * len(recs))(*recs)
+            # The kernel adds into dW / db with plain read-modify-write, one workgroup per (record, tile): two records with the
+            # SAME destination (a module applied more than once per backward pass -- the discriminator sees style, content
+            # and class embeddings, losses.py:89-104) must not share a launch.  Round r holds the r-th use of every weight;
+            # rounds run back to back on the stream, so the sum order is fixed (bit-reproducible).
+            rounds, seen = [], {}
+            for rec in recs:
+                r = seen.get(rec.dW, 0)
+                seen[rec.dW] = r + 1
+                if r == len(rounds):
+                    rounds.append([])
+                rounds[r].append(rec)
             # records go to the kernel BY VALUE (kernel arguments): no device table, no H2D copy node in the captured step;
             # the operand tensors are kept alive for graph replays
             if torch.cuda.is_current_stream_capturing():
                 self._pinned.append(items)
-            check(lib().ast_linear_wgrad_batched_host(C.addressof(arr), len(recs), max_tiles, stream()), "ast_linear_wgrad_batched_host")
+            for rr in rounds:
+                arr = (LinWg * len(rr))(*rr)
+                check(lib().ast_linear_wgrad_batched_host(C.addressof(arr), len(rr), max_tiles, stream()), "ast_linear_wgrad_batched_host")
 
 
 def img_dtype():

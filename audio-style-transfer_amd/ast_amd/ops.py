@@ -919,21 +919,41 @@ def nchw_to_nhwc(x4, dtype, Cp=None):
     return y
 
 
-_nhwc_cache = {}
+class _SharedInput:
+    """The NHWC image of the step's input, shared by the modules that read the same x (both encoders).
+
+    Set by `shared_nhwc(x)` for the duration of ONE forward pass and dropped at its end: the conversion kernel is
+    launched inside the step that uses it (so a hipGraph capture records it and the image lives in the graph's pool),
+    and nothing survives into the next step -- a later step on new values of the same tensor object converts again."""
+    x = None
+    y = None
+    dtype = None
+
+
+class shared_nhwc:
+    """with shared_nhwc(x5, dtype): ...   -- encoders called inside find the (B*S,T,F,Cp) image of x5 ready."""
+
+    def __init__(self, x5, dtype):
+        self.x5, self.dtype = x5, dtype
+
+    def __enter__(self):
+        B, S, C, T, F = self.x5.shape
+        _SharedInput.x, _SharedInput.dtype = self.x5, self.dtype
+        _SharedInput.y = nchw_to_nhwc(self.x5.view(B * S, C, T, F), self.dtype)
+        return _SharedInput.y
+
+    def __exit__(self, *exc):
+        _SharedInput.x = _SharedInput.y = _SharedInput.dtype = None
+        return False
 
 
 def cached_nhwc(x5, dtype):
-    """(B,S,C,T,F) f32 -> (B*S,T,F,Cp) NHWC.  Both encoders read the same x: convert it once per
-    (tensor object, version, dtype).  Keyed on object identity (weakref), not on the address, so a new
-    tensor that reuses the storage never hits a stale entry."""
-    import weakref
-    hit = _nhwc_cache.get("k")
-    if hit is not None and hit[0]() is x5 and hit[1] == (x5._version, dtype):
-        return hit[2]
+    """(B,S,C,T,F) f32 -> (B*S,T,F,Cp) NHWC: the image a surrounding `shared_nhwc(x5)` scope prepared, else a fresh
+    conversion (no state is kept between calls)."""
+    if _SharedInput.x is x5 and _SharedInput.dtype == dtype:
+        return _SharedInput.y
     B, S, C, T, F = x5.shape
-    y = nchw_to_nhwc(x5.view(B * S, C, T, F), dtype)
-    _nhwc_cache["k"] = (weakref.ref(x5), (x5._version, dtype), y)
-    return y
+    return nchw_to_nhwc(x5.view(B * S, C, T, F), dtype)
 
 
 class CastFn(torch.autograd.Function):

@@ -118,11 +118,12 @@ class FlatGroup:
 
 
 class Trainer:
-    def __init__(self, cfg: TrainConfig = None, device="cuda:0", rank=0, world=1, seed=1234, init="reference"):
+    def __init__(self, cfg: TrainConfig = None, device="cuda:0", rank=0, world=1, seed=1234, init="unit_gammas"):
         self.cfg = cfg or TrainConfig()
         self.device = torch.device(device)
         self.rank, self.world = rank, world
         torch.manual_seed(seed)                      # identical replicas on every rank
+        ops._DropState.seed = 0x5EED + 1000003 * int(rank)   # ... but independent dropout masks: ranks hold different clips
         self.style, self.content = StyleEncoder(), ContentEncoder()
         self._simple = self.cfg.decoder == "simple"
         if self._simple:
@@ -131,9 +132,11 @@ class Trainer:
         else:
             self.decoder, self._rec_loss = Decoder(), compute_comprehensive_loss
         self.disc = Discriminator()
-        if init == "reference":
-            # a freshly built reference decoder has all BN/LN gammas = 0 and outputs 0:
-            # give the gammas their conventional value 1 so the step does real work
+        if init in ("reference", "unit_gammas"):
+            # NOT the reference's initial state: a freshly built reference decoder has all BN/LN gammas = 0 and
+            # outputs exactly 0 (new_decoder.py:134-143).  "unit_gammas" (the default; "reference" is the
+            # old name of the same thing) gives the decoder gammas their conventional value 1 so the step does real
+            # work; init="as_constructed" keeps the reference's zeros.
             with torch.no_grad():
                 for name, p in self.decoder.named_parameters():
                     if p.dim() == 1 and "weight" in name:
@@ -167,6 +170,7 @@ class Trainer:
         self._parts = None
         self._frontend = None
         self._frontend_cqt = None
+        self._fe_bufs = {}
         self._static = None
         self.losses = {}
 
@@ -179,6 +183,16 @@ class Trainer:
             ops._DropState.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         check(lib().ast_counter_incr(ptr(ops._DropState.counter), stream()), "ast_counter_incr")
         y = x[..., :513]
+        with ops.shared_nhwc(x, config.compute_dtype):      # one input conversion for both encoders, inside this step
+            style_emb, class_emb, content_emb, y_emb = self._encoders(x, y, labels_host)
+        self._y_emb = y_emb
+        if defer_d:
+            return y, style_emb, class_emb, content_emb, None
+        d_loss = self._d_phase(style_emb, class_emb, content_emb, labels_host)
+        return y, style_emb, class_emb, content_emb, d_loss
+
+    def _encoders(self, x, y, labels_host):
+        c = self.cfg
         y_emb = None
         if c.multi_stream:
             # three mutually independent CNN branches: run them concurrently (forward here; autograd replays
@@ -187,9 +201,10 @@ class Trainer:
             if self._streams is None:
                 self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
             s1, s2, s3 = self._streams
-            ops.cached_nhwc(x, config.compute_dtype)          # shared input conversion, before the fork
-            for st in self._streams:
+            for st in self._streams:                 # fork after the shared input conversion (shared_nhwc, on main)
                 st.wait_stream(main)
+                if ops._SharedInput.y is not None:
+                    ops._SharedInput.y.record_stream(st)
             order = os.environ.get("AST_BRANCH_ORDER", "ysc")   # creation order = reverse backward priority; y first measured 0.03 ms better
             for b in order:
                 if b == "s":
@@ -217,11 +232,7 @@ class Trainer:
         else:
             style_emb, class_emb = self.style(x, labels_host)
             content_emb = self.content(x)
-        self._y_emb = y_emb
-        if defer_d:
-            return y, style_emb, class_emb, content_emb, None
-        d_loss = self._d_phase(style_emb, class_emb, content_emb, labels_host)
-        return y, style_emb, class_emb, content_emb, d_loss
+        return style_emb, class_emb, content_emb, y_emb
 
     def _d_phase(self, style_emb, class_emb, content_emb, labels_host):
         """Discriminator step on the detached embeddings (losses.py:69-79 compute_for_discriminator=True)."""
@@ -374,9 +385,22 @@ class Trainer:
     def set_frontend(self, waves, mean, std, cqt_mean=None, cqt_std=None):
         """Make the STFT front-end part of the step: every step() first runs the fused STFT + z-score +
         sectioning kernel (utilityFunctions.py:12-37,240-263; dataloader.py:9-13) from these device-resident
-        waveforms straight into bins [0,513) of x (the collate layout of dataloader.py:123-147)."""
-        self._frontend = (waves.contiguous(), mean.contiguous(), std.contiguous())
-        self._frontend_cqt = None if cqt_mean is None else (cqt_mean.contiguous(), cqt_std.contiguous())
+        waveforms straight into bins [0,513) of x (the collate layout of dataloader.py:123-147).
+
+        The Trainer OWNS its front-end buffers: calling this again with tensors of the same shapes (a new batch of
+        waveforms, other statistics) copies into them, so captured graphs -- which bake the buffer addresses in --
+        read the new values on their next replay.  New shapes get new buffers, and the graph cache key (which holds
+        the buffer addresses) makes step() capture again."""
+        def own(slot, t):
+            t = t.detach()
+            cur = self._fe_bufs.get(slot)
+            if cur is None or cur.shape != t.shape or cur.dtype != t.dtype or cur.device != t.device:
+                cur = self._fe_bufs[slot] = t.contiguous().clone()
+            elif cur.data_ptr() != t.data_ptr():
+                cur.copy_(t)
+            return cur
+        self._frontend = (own("waves", waves), own("mean", mean), own("std", std))
+        self._frontend_cqt = None if cqt_mean is None else (own("cqt_mean", cqt_mean), own("cqt_std", cqt_std))
 
     def _run_frontend(self, x):
         if self._frontend is None:
@@ -396,8 +420,7 @@ class Trainer:
             self.losses = self._step_body(x, labels_host)
             return self.losses
         segmented = self.world > 1 or self.cfg.segmented
-        key = (tuple(x.shape), tuple(labels_host.tolist()), config.compute_dtype, self.cfg.use_nce, self.cfg.use_hsic,
-               self.cfg.use_adv, segmented)
+        key = self._graph_key(x, labels_host, segmented)
         if key not in self._graphs:
             self._capture(key, x, labels_host, segmented)
         graphs, static_x, outs = self._graphs[key]
@@ -413,6 +436,36 @@ class Trainer:
             graphs[2].replay()
         self.losses = outs
         return outs
+
+    def sync_buffers(self):
+        """Data parallel, default mode: every rank's BatchNorm running statistics follow its own shard.  Average them
+        over ranks (and keep rank 0's integer counters) so that a checkpoint reflects the global batch stream."""
+        if self.world <= 1:
+            return
+        for m in (self.style, self.content, self.decoder, self.disc):
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm) and mod.running_mean is not None:
+                    for t in (mod.running_mean, mod.running_var):
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                        t.div_(self.world)
+
+    def save_checkpoint(self, path, **extra):
+        """The reference's four-state_dict .pth (evaluation_style_transfer.py:246-252), written by rank 0 after
+        sync_buffers()."""
+        from .checkpoint import save_checkpoint
+        self.sync_buffers()
+        if self.rank == 0:
+            save_checkpoint(path, self.content, self.style, self.decoder, self.disc, **extra)
+
+    def _graph_key(self, x, labels_host, segmented):
+        """Everything a captured step bakes in: shapes, labels (host-side class layout), dtype, curriculum gates, the
+        optimiser / clipping / loss-weight scalars (kernel arguments) and the front-end buffer addresses.  Changing any
+        of them between steps (an LR schedule, the curriculum, attaching a front end) captures a new graph instead of
+        silently replaying the old values."""
+        c = self.cfg
+        fe = tuple(t.data_ptr() for t in (self._frontend or ())) + tuple(t.data_ptr() for t in (self._frontend_cqt or ()))
+        return (tuple(x.shape), tuple(labels_host.tolist()), config.compute_dtype, c.use_nce, c.use_hsic, c.use_adv, segmented,
+                c.lr_g, c.lr_d, tuple(c.betas), c.eps, c.max_grad_norm, c.w_rec, c.w_nce, c.w_margin, c.w_hsic, c.w_adv, fe)
 
     def _mutable_state(self):
         ts = [self.G.flat_p, self.G.m, self.G.v, self.G.step, self.D.flat_p, self.D.m, self.D.v, self.D.step]

@@ -38,9 +38,39 @@ class Cfg:
     dropout probability used where the reference has nn.Dropout(0.1) -- parity
     runs use 0.0 because torch's RNG stream is not part of the contract."""
 
-    def __init__(self, training: bool = True, p_drop: float = 0.0):
+    def __init__(self, training: bool = True, p_drop: float = 0.0, act_dtype=None):
         self.training = training
         self.p_drop = p_drop
+        # None: the fp32 reference arithmetic.  torch.bfloat16: additionally ROUND every image activation (and its
+        # gradient) and every packed conv weight to bf16 at the points where the HIP bf16 compute mode stores them
+        # (conv outputs, BN(+ReLU) / ResBlock-tail / pooling outputs; accumulation, statistics, token tensors and
+        # weight gradients stay f32) -- an emulation of that mode's storage precision, used to tell rounding that is
+        # inherent to bf16 storage from kernel error (tests/test_gpu_bench_config.py, tools/bf16_grad_ablation.py).
+        self.act_dtype = act_dtype
+
+
+class _RoundST(torch.autograd.Function):
+    """y = round_to(dtype)(x) forward; the incoming gradient is rounded the same way backward (both are stored in
+    that dtype by the emulated path)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype, round_grad):
+        ctx.dtype, ctx.round_grad = dtype, round_grad
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(ctx.dtype).to(g.dtype) if ctx.round_grad else g), None, None
+
+
+def _q(x, cfg: Cfg):
+    """activation storage point"""
+    return x if cfg.act_dtype is None else _RoundST.apply(x, cfg.act_dtype, True)
+
+
+def _qw(w, cfg: Cfg):
+    """packed-weight storage point (the weight GRADIENT is accumulated in f32: no rounding backward)"""
+    return w if cfg.act_dtype is None else _RoundST.apply(w, cfg.act_dtype, False)
 
 
 def _drop(x, cfg: Cfg):
@@ -71,13 +101,13 @@ def spectral_weight(sd, prefix: str, cfg: Cfg, dim: int = 0):
 
 
 def conv_sn(sd, prefix, x, cfg, stride=1, padding=0):
-    return F.conv2d(x, spectral_weight(sd, prefix, cfg), sd[prefix + "bias"], stride=stride, padding=padding)
+    return _q(F.conv2d(x, _qw(spectral_weight(sd, prefix, cfg), cfg), sd[prefix + "bias"], stride=stride, padding=padding), cfg)
 
 
 def convT_sn(sd, prefix, x, cfg, stride=1, padding=0, output_padding=0):
-    w = spectral_weight(sd, prefix, cfg, dim=1)
-    return F.conv_transpose2d(x, w, sd[prefix + "bias"], stride=stride, padding=padding,
-                              output_padding=output_padding)
+    w = _qw(spectral_weight(sd, prefix, cfg, dim=1), cfg)
+    return _q(F.conv_transpose2d(x, w, sd[prefix + "bias"], stride=stride, padding=padding,
+                                 output_padding=output_padding), cfg)
 
 
 # --------------------------------------------------------------------------
@@ -220,20 +250,21 @@ def resblock(sd, prefix, x, cfg, stride=2):
     idn = conv_sn(sd, prefix + "downsample.0.", x, cfg, stride=stride, padding=0)
     idn = instancenorm2d(sd, prefix + "downsample.1.", idn)
     out = conv_sn(sd, prefix + "conv1.", x, cfg, stride=stride, padding=1)
-    out = torch.relu(batchnorm2d(sd, prefix + "bn1.", out, cfg))
+    out = _q(torch.relu(batchnorm2d(sd, prefix + "bn1.", out, cfg)), cfg)
     out = conv_sn(sd, prefix + "conv2.", out, cfg, stride=1, padding=1)
     out = batchnorm2d(sd, prefix + "bn2.", out, cfg)
-    return torch.relu(out + idn)
+    return _q(torch.relu(out + idn), cfg)
 
 
 def deep_cnn(sd, net_prefix, proj_prefix, x, cfg, nblocks=6, return_blocks=False):
     """style_encoder.py:95-129 / content_encoder.py:22-46,80-85."""
     feats = []
+    x = _q(x, cfg)
     for i in range(nblocks):
         x = resblock(sd, f"{net_prefix}{i}.", x, cfg)
         feats.append(x)
-    x = adaptive_avg_pool2d(x, (2, 5))
-    x = adaptive_avg_pool2d(x, (1, 1)).flatten(1)
+    x = _q(adaptive_avg_pool2d(x, (2, 5)), cfg)
+    x = _q(adaptive_avg_pool2d(x, (1, 1)), cfg).flatten(1)
     out = linear(sd, proj_prefix, x)
     return (out, feats) if return_blocks else out
 
@@ -275,13 +306,13 @@ def content_encoder_forward(sd, x, cfg, nhead=4, nlayers=4):
 # --------------------------------------------------------------------------
 def decoder_encode_input(sd, y, cfg):
     """new_decoder.py:145-168 -- y: (N,2,287,513) -> (N,256)."""
-    h = y
+    h = _q(y, cfg)
     for idx, stride in ((0, 1), (3, 2), (6, 2), (9, 2)):
         h = conv_sn(sd, f"conv_encoder.{idx}.", h, cfg, stride=stride, padding=1)
-        h = torch.relu(batchnorm2d(sd, f"conv_encoder.{idx + 1}.", h, cfg))
-    h = adaptive_avg_pool2d(h, (32, 16))
+        h = _q(torch.relu(batchnorm2d(sd, f"conv_encoder.{idx + 1}.", h, cfg)), cfg)
+    h = _q(adaptive_avg_pool2d(h, (32, 16)), cfg)
     h = conv_sn(sd, "spatial_projection.0.", h, cfg, stride=1, padding=1)
-    h = torch.relu(batchnorm2d(sd, "spatial_projection.1.", h, cfg))
+    h = _q(torch.relu(batchnorm2d(sd, "spatial_projection.1.", h, cfg)), cfg)
     h = conv_sn(sd, "spatial_projection.3.", h, cfg, stride=1, padding=0)
     return linear(sd, "feature_to_sequence.", h.flatten(1))
 
@@ -289,10 +320,10 @@ def decoder_encode_input(sd, y, cfg):
 def decoder_generate_output(sd, tok, cfg):
     """new_decoder.py:170-193 -- tok: (B,S,256) -> (B,S,2,287,513)."""
     B, S, _ = tok.shape
-    h = linear(sd, "sequence_to_feature.", layernorm(sd, "output_norm.", tok)).view(B * S, 1, 32, 16)
+    h = _q(linear(sd, "sequence_to_feature.", layernorm(sd, "output_norm.", tok)).view(B * S, 1, 32, 16), cfg)
     for idx in (0, 3, 6, 9):
         h = convT_sn(sd, f"conv_decoder.{idx}.", h, cfg, stride=2, padding=1, output_padding=1)
-        h = torch.relu(batchnorm2d(sd, f"conv_decoder.{idx + 1}.", h, cfg))
+        h = _q(torch.relu(batchnorm2d(sd, f"conv_decoder.{idx + 1}.", h, cfg)), cfg)
     h = convT_sn(sd, "conv_decoder.12.", h, cfg, stride=1, padding=1)
     return bilinear_resize(h, (287, 513)).view(B, S, 2, 287, 513)
 

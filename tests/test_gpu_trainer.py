@@ -144,3 +144,112 @@ def test_trainer_with_simple_decoder_graph_matches_eager():
         for k in a:
             assert math.isfinite(a[k]) and math.isclose(a[k], b[k], rel_tol=5e-3, abs_tol=1e-5), (k, a[k], b[k])
     assert res[0][1]["rec"] != res[0][0]["rec"]
+
+
+def _seq_losses(tr, batches, labels):
+    hist = []
+    for x in batches:
+        hist.append({k: float(v) for k, v in tr.step(x, labels).items()})
+    torch.cuda.synchronize()
+    return hist
+
+
+def test_graph_replays_read_each_new_batch():
+    """A replayed step must see the values of the batch it is given (the captured graph contains the input layout
+    conversion; nothing is cached across steps): graph vs eager over three DISTINCT batches."""
+    ast_amd.set_compute_dtype(torch.float32)
+    labels = train.synthetic_batch(4, 1, "cuda:0", seed=3)[1]
+    batches = [train.synthetic_batch(4, 1, "cuda:0", seed=s)[0] for s in (3, 4, 5)]
+    batches[2] = 3.0 * batches[2]                                     # make the third one unmistakably different
+    eager = _seq_losses(train.Trainer(train.TrainConfig(use_graph=False, multi_stream=False, dropout=False), seed=7), batches, labels)
+    graph = _seq_losses(train.Trainer(train.TrainConfig(use_graph=True, dropout=False), seed=7), batches, labels)
+    assert abs(eager[2]["rec"] - eager[0]["rec"]) > 0.1 * abs(eager[0]["rec"])        # the batches do differ
+    for i, (g, e) in enumerate(zip(graph, eager)):
+        for k in e:
+            tol = 5e-3 if i > 0 else (2e-3 if k in ("adv_g", "total") else 2e-4)
+            assert math.isclose(g[k], e[k], rel_tol=tol, abs_tol=1e-5), (i, k, g[k], e[k])
+
+
+def test_inference_session_reads_each_new_clip():
+    from ast_amd import infer
+    from ast_amd.content_encoder import ContentEncoder
+    from ast_amd.new_decoder import Decoder
+    from oracle import seeded_params as sp
+    ast_amd.set_compute_dtype(torch.float32)
+    ce, de = ContentEncoder(), Decoder()
+    ce.load_state_dict(sp.seeded_state_dict(ce.state_dict(), tag="content"))      # non-degenerate parameters: a fresh
+    de.load_state_dict(sp.seeded_state_dict(de.state_dict(), tag="decoder"))      # decoder outputs 0 (SURVEY F7)
+    ce, de = ce.cuda().train(), de.cuda().train()
+    cls = sp.seeded_normal((2, 256), 77).cuda()
+    # eval mode normalises with the BatchNorm running statistics: make them those of real activations (one training
+    # forward with momentum 1), otherwise the seeded running stats let the activations explode and the output barely
+    # depends on the clip
+    x0 = sp.seeded_input(2, 2, seed=9).cuda()
+    bns = [m for mod in (ce, de) for m in mod.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    for m in bns:
+        m.momentum = 1.0
+    with torch.no_grad():
+        de(ce(x0), cls, y=x0[..., :513])
+    for m in bns:
+        m.momentum = 0.1
+    eager = infer.StyleTransferSession(ce, de, use_graph=False)
+    graph = infer.StyleTransferSession(ce, de, use_graph=True)
+    outs = []
+    for i, seed in enumerate((1, 2)):
+        x = (1.0 + 2.0 * i) * sp.seeded_input(2, 2, seed=seed).cuda()
+        w_e, o_e = eager(x, cls)
+        w_g, o_g = graph(x, cls)
+        err = float((o_g - o_e).abs().max()) / float(o_e.abs().max())
+        assert err < 1e-4, (seed, err)
+        outs.append(o_e.clone())
+    # different clips, different outputs (a graph that kept reading the first clip would fail the line above)
+    diff = float((outs[0] - outs[1]).abs().max()) / float(outs[0].abs().max())
+    assert diff > 1e-2, diff
+
+
+def test_train_eval_train_on_one_module():
+    """An eval / no-grad forward between two training steps (validation, an inference session) must leave the
+    training-side weight-gradient staging intact."""
+    ast_amd.set_compute_dtype(torch.float32)
+    torch.manual_seed(2)
+    enc = ast_amd.ContentEncoder().cuda().train()
+    x = torch.randn(2, 1, 2, 287, 597, device="cuda")
+
+    def train_pass():
+        for p in enc.parameters():
+            p.grad = None
+        enc(x).square().mean().backward()
+        torch.cuda.synchronize()
+        return float(enc.cnn[0].conv1.weight_orig.grad.norm())
+    g0 = train_pass()
+    enc.eval()
+    with torch.no_grad():
+        enc(x)
+    enc.train()
+    g1 = train_pass()                     # raised "weights were prepared in eval/no-grad mode" before the fix
+    assert g0 > 0 and math.isfinite(g1)
+    # (the values differ slightly: BN running stats are not used in training mode, but the spectral-norm u, v advanced)
+    assert math.isclose(g0, g1, rel_tol=0.2)
+
+
+def test_set_frontend_per_batch_under_graph():
+    """set_frontend() with a NEW batch of waveforms between replayed steps: the trainer owns the front-end buffers, so
+    the captured graph reads the new clips (eager and graph agree step by step)."""
+    ast_amd.set_compute_dtype(torch.float32)
+    w1, x, mean, std, labels = train.synthetic_waveform_batch(2, 4.0, "cuda:0", seed=9)
+    w2 = train.synthetic_waveform_batch(2, 4.0, "cuda:0", seed=21)[0]
+    res = []
+    for use_graph in (False, True):
+        tr = train.Trainer(train.TrainConfig(use_graph=use_graph, dropout=False), seed=3)
+        h = []
+        for w in (w1, w2, 0.5 * w1):
+            tr.set_frontend(w, mean, std)
+            h.append({k: float(v) for k, v in tr.step(x.clone(), labels).items()})
+        res.append(h)
+        if use_graph:
+            assert len(tr._graphs) == 1               # same buffers, one capture
+    assert abs(res[0][1]["rec"] - res[0][0]["rec"]) > 1e-3
+    for i, (e, g) in enumerate(zip(*res)):
+        for k in e:
+            tol = 5e-3 if i > 0 else (2e-3 if k in ("adv_g", "total") else 2e-4)
+            assert math.isclose(e[k], g[k], rel_tol=tol, abs_tol=1e-5), (i, k, e[k], g[k])
