@@ -1024,6 +1024,264 @@ int launch_wgrad_halo(const void* dy, const void* src, float* dw, const ast_gath
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Patch-staged convolution GEMM ("pconv") for multi-tap, stride-1 gathers (3x3 convolutions forward and data
+// gradient, the output-parity classes of stride-2 data gradients / transposed convolutions).
+//
+// Why: the gathered kernel above fetches every source pixel once per TAP through the vector-memory path (im2col in the
+// TA) and writes it to LDS once per tap.  Measured (tools/micro/fragbench.hip, ldbench.hip): that path delivers 57 B/clk/CU
+// only for wave-contiguous kilobytes and 26 B/clk/CU for 64-byte row pieces at a pitch >= 128 B, and ds_write moves
+// 64 B/clk/CU -- at 9 taps both cost more cycles than the MFMAs they feed.  Here a workgroup owns a 2-D tile of output
+// pixels (128 = 8 fragments of 16 consecutive pixels of one row) x BN channels and stages the source PATCH (tile + halo)
+// once per 64-channel slab: every pixel crosses L1 and the LDS write port once, in whole contiguous rows.  A tap is then a
+// constant pixel offset into the patch: the B fragment of (tap, pixel fragment) is one ds_read_b128 at a shifted
+// address.  Only the weights (BN x 128 B per tap and slab) stream through a double-buffered LDS stage, one barrier per
+// tap.  Waves split the tile's fragments (TM each) and every wave covers all TN channel tiles: TM + TN fragment reads
+// per TM*TN MFMAs.
+//
+// LDS images: pixel (or weight row) p at p*SLB, its 16-byte chunk c stored at chunk c ^ H(p), H(p) = p & 7 for
+// 128-byte pixels, (p >> 1) & 3 for 64-byte pixels: with ds_read_b128's 16-lane groups this is conflict-free for ANY
+// fragment base pixel (brute-forced over all bases), which the per-tap shifts need.
+// ---------------------------------------------------------------------------
+constexpr int PC_MAXPL = 8;          // patch chunks (16 B) per thread
+struct PconvPlan { int TH, TWF, PH, PW, dhmin, dwmin, tiles_h, tiles_w, nct, lds; float rcp_nct, rcp_per_img, rcp_tiles_w, rcp_pw, rcp_twf; };
+
+template <int SLB> __device__ __forceinline__ int pc_h(int p) { return SLB == 128 ? (p & 7) : ((p >> 1) & 3); }
+
+template <typename T, int SLB, int TM, int TN>
+__global__ __launch_bounds__(256) void pconv_kernel(const T* __restrict__ src, const T* __restrict__ wgt, const float* __restrict__ bias,
+                                                    T* __restrict__ dst, const ast_gather_t g, const PconvPlan pp, const int flags,
+                                                    float* __restrict__ ws, const unsigned src_bytes, const unsigned wgt_bytes,
+                                                    const T* __restrict__ bn_x, const float* __restrict__ bn_scale,
+                                                    const float* __restrict__ bn_shift) {
+  constexpr int ES = sizeof(T);
+  constexpr int CPP = SLB / 16;                  // 16-byte chunks per pixel (and per weight row) per slab
+  constexpr int BN = TN * 16;
+  constexpr int NWL = (BN * CPP + 255) / 256;    // weight chunks per thread per stage
+  constexpr int KS = SLB / 64;                   // MFMA K steps (64 B of a row) per (tap, slab)
+  constexpr unsigned OOB = 0x80000000u;
+  using frag = typename Mma<T>::frag;
+  extern __shared__ __attribute__((aligned(16))) unsigned char pl[];
+  const int patch_bytes = pp.PH * pp.PW * SLB;
+  unsigned char* wbuf = pl + patch_bytes;        // two stages of BN x SLB
+  int* taptab = reinterpret_cast<int*>(wbuf + 2 * BN * SLB);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int chunk = gridDim.x >> 3;              // XCD-aware order, as igemm_kernel
+  const int tix = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  const int per_img = pp.tiles_h * pp.tiles_w;
+  if (tix >= g.N * per_img * pp.nct) return;
+  // (reciprocal division: three integer divisions by run-time values cost ~100 VALU per wave, as much as two taps)
+  const int st = fdiv(tix, pp.nct, pp.rcp_nct), ct = tix - st * pp.nct;      // channel tiles of one spatial tile are neighbours (same patch in L2)
+  const int n = fdiv(st, per_img, pp.rcp_per_img), r = st - n * per_img;
+  const int th = fdiv(r, pp.tiles_w, pp.rcp_tiles_w), tw = r - th * pp.tiles_w;
+  const int TWP = pp.TWF * 16;
+  const int hm0 = th * pp.TH, wm0 = tw * TWP;
+  const int bn0 = ct * BN;
+  const int hs_org = hm0 + g.oh + pp.dhmin, ws_org = wm0 + g.ow + pp.dwmin;      // stride-1 gathers only (plan_pconv)
+  const __amdgpu_buffer_rsrc_t srcR = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wgtR = __builtin_amdgcn_make_buffer_rsrc((void*)wgt, 0, wgt_bytes, 0x00020000);
+
+#pragma unroll
+  for (int t = 0; t < AST_MAX_TAPS; ++t)
+    if (tid == t) {
+      int dh, dw, wt;
+      decode_tap(g.tap[t], dh, dw, wt);
+      taptab[t] = (dh - pp.dhmin) * pp.PW + (dw - pp.dwmin);       // patch pixel offset of the tap
+      taptab[16 + t] = wt * g.Cs * ES;                             // byte offset of the tap's weight slice in a weight row
+    }
+
+  // ---- loader descriptors (this workgroup's tile: fixed for the whole kernel).  Chunk i of thread t is chunk t % CPP of
+  // patch pixel t / CPP + i * (256 / CPP): the pixel coordinates advance incrementally (one division in all).
+  unsigned goff[PC_MAXPL];
+  int lofs[PC_MAXPL];
+  {
+    constexpr int PSTEP = 256 / CPP;             // patch pixels between a thread's consecutive chunks
+    const int npix = pp.PH * pp.PW;
+    const int c = tid % CPP;
+    int pix = tid / CPP;
+    int py = fdiv(pix, pp.PW, pp.rcp_pw), px = pix - py * pp.PW;
+    const int gbase = (((n * g.Hs + hs_org) * g.Ws + ws_org) * g.Cs) * ES + c * 16;
+#pragma unroll
+    for (int i = 0; i < PC_MAXPL; ++i) {
+      const bool in_patch = pix < npix;
+      const bool in_img = (unsigned)(hs_org + py) < (unsigned)g.Hs && (unsigned)(ws_org + px) < (unsigned)g.Ws;
+      goff[i] = (in_patch && in_img) ? (unsigned)(gbase + ((py * g.Ws + px) * g.Cs) * ES) : OOB;
+      lofs[i] = in_patch ? pix * SLB + ((c ^ pc_h<SLB>(pix)) << 4) : -1;
+      pix += PSTEP; px += PSTEP;
+      if (px >= pp.PW) { px -= pp.PW; ++py; }    // PW >= 16 + halo and PSTEP <= 64: at most four wraps
+      if (px >= pp.PW) { px -= pp.PW; ++py; }
+      if (PSTEP > 32) { if (px >= pp.PW) { px -= pp.PW; ++py; } if (px >= pp.PW) { px -= pp.PW; ++py; } }
+    }
+  }
+  unsigned woff[NWL];
+  int wl[NWL];
+#pragma unroll
+  for (int k = 0; k < NWL; ++k) {
+    const int idx = tid + 256 * k;
+    const int c = idx % CPP, row = idx / CPP;
+    const bool ok = row < BN && bn0 + row < g.Cd;
+    woff[k] = ok ? (unsigned)(((bn0 + row) * g.wtaps * g.Cs) * ES + c * 16) : OOB;
+    wl[k] = row < BN ? row * SLB + ((c ^ pc_h<SLB>(row)) << 4) : -1;
+  }
+  // ---- fragment addresses
+  int aoff[TN];                                   // weight rows i*16 + fr: H(row) = H(fr)
+#pragma unroll
+  for (int i = 0; i < TN; ++i) aoff[i] = (i * 16 + fr) * SLB + ((fq ^ pc_h<SLB>(fr)) << 4);
+  int pb[TM];                                     // patch pixel of this lane's output pixel (before the tap offset)
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int f = __builtin_amdgcn_readfirstlane(wave) * TM + j;      // wave-uniform: scalar arithmetic
+    const int ty = fdiv(f, pp.TWF, pp.rcp_twf), tx = (f - ty * pp.TWF) * 16 + fr;
+    pb[j] = ty * pp.PW + tx;
+  }
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  __syncthreads();                                // taptab
+  const int nslab = (g.Cs * ES) / SLB;
+  u32x4 wr[NWL];
+  for (int s = 0; s < nslab; ++s) {
+    const unsigned sb = (unsigned)(s * SLB);
+    {
+      u32x4 pr[PC_MAXPL];
+#pragma unroll
+      for (int i = 0; i < PC_MAXPL; ++i) pr[i] = __builtin_amdgcn_raw_buffer_load_b128(srcR, goff[i] + sb, 0, 0);
+      const unsigned w0 = (unsigned)__builtin_amdgcn_readfirstlane(taptab[16]) + sb;
+#pragma unroll
+      for (int k = 0; k < NWL; ++k) wr[k] = __builtin_amdgcn_raw_buffer_load_b128(wgtR, woff[k] + w0, 0, 0);
+      // (the previous slab's last tap ended with a barrier: every read of the patch and of stage 0 is done)
+#pragma unroll
+      for (int i = 0; i < PC_MAXPL; ++i)
+        if (lofs[i] >= 0) *reinterpret_cast<u32x4*>(pl + lofs[i]) = pr[i];
+#pragma unroll
+      for (int k = 0; k < NWL; ++k)
+        if (wl[k] >= 0) *reinterpret_cast<u32x4*>(wbuf + wl[k]) = wr[k];
+    }
+    __syncthreads();
+    for (int t = 0; t < g.ntaps; ++t) {
+      const int cur = t & 1;
+      const bool more = t + 1 < g.ntaps;
+      if (more) {
+        const unsigned wn = (unsigned)__builtin_amdgcn_readfirstlane(taptab[16 + t + 1]) + sb;
+#pragma unroll
+        for (int k = 0; k < NWL; ++k) wr[k] = __builtin_amdgcn_raw_buffer_load_b128(wgtR, woff[k] + wn, 0, 0);
+      }
+      const int toff = __builtin_amdgcn_readfirstlane(taptab[t]);
+      const unsigned char* wcur = wbuf + cur * (BN * SLB);
+      int xa[TM];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int p = pb[j] + toff;
+        xa[j] = p * SLB + ((fq ^ pc_h<SLB>(p)) << 4);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        frag wf[TN], xf[TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const frag*>(wcur + (aoff[i] ^ (ks << 6)));
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const frag*>(pl + (xa[j] ^ (ks << 6)));
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+      }
+      if (more) {
+        unsigned char* wnext = wbuf + (cur ^ 1) * (BN * SLB);
+#pragma unroll
+        for (int k = 0; k < NWL; ++k)
+          if (wl[k] >= 0) *reinterpret_cast<u32x4*>(wnext + wl[k]) = wr[k];
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (shared with igemm_kernel): lane owns pixel fr of fragment j, channels fq*4.. of channel tile i
+  const bool accumulate = flags & 1, relu = flags & 2, stats = flags & 8, bstats = flags & 16, bn_relu = !(flags & 32);
+  EpiCtx<T> ec{dst, bias, ws, bn_x, bn_scale, bn_shift, g.Hm * g.Wm, 0.f, 0.f, accumulate, relu, stats, bstats, bn_relu};
+  float st1[TN][4], st2[TN][4];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { st1[i][q] = 0.f; st2[i][q] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int f = __builtin_amdgcn_readfirstlane(wave) * TM + j;
+    const int ty = fdiv(f, pp.TWF, pp.rcp_twf), tx = (f - ty * pp.TWF) * 16 + fr;
+    const int hm = hm0 + ty, wq = wm0 + tx;
+    if (hm >= g.Hm || wq >= g.Wm) continue;
+    f32x4 col[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) col[i] = acc[i][j];
+    epi_store<T, TN>(ec, g, col, (size_t)(n * g.Hd + hm * g.dsh + g.doh) * g.Wd + (wq * g.dsw + g.dow), bn0 + fq * 4, st1, st2);
+  }
+  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, tix, bn0, fr, fq);
+}
+
+// Tile plan of the patch kernel, or false when the geometry should stay on the gathered kernel.
+bool plan_pconv(const ast_gather_t& g, int dtype, PconvPlan& pp, int& slb, int& tn) {
+  const char* en = getenv("AST_PCONV");                      // read per call (host side only): tests toggle it at run time
+  if ((en && atoi(en) == 0) || g.ntaps < 2 || g.sh != 1 || g.sw != 1) return false;
+  const int ES = dtype == AST_BF16 ? 2 : 4;
+  const int rowb = g.Cs * ES;
+  if (rowb % 64) return false;
+  slb = (rowb % 128 == 0) ? 128 : 64;
+  if (g.Cd < 32) return false;
+  tn = g.Cd >= 64 ? 4 : 2;
+  int dhmin = 64, dhmax = -64, dwmin = 64, dwmax = -64;
+  for (int t = 0; t < g.ntaps; ++t) {
+    const int dh = (g.tap[t] & 255) - 64, dw = ((g.tap[t] >> 8) & 255) - 64;
+    dhmin = std::min(dhmin, dh); dhmax = std::max(dhmax, dh); dwmin = std::min(dwmin, dw); dwmax = std::max(dwmax, dw);
+  }
+  const int cpp = slb / 16;
+  double best = 0.0;
+  for (int twf = 1; twf <= 8; twf *= 2) {                         // 8 fragments per workgroup: 8x16, 4x32, 2x64, 1x128 pixels
+    const int th = 8 / twf, twp = twf * 16;
+    const int ph = th + (dhmax - dhmin), pw = twp + (dwmax - dwmin);
+    if (ph * pw * cpp > 256 * PC_MAXPL) continue;
+    const int tiles_h = (g.Hm + th - 1) / th, tiles_w = (g.Wm + twp - 1) / twp;
+    const double eff = (double)g.Hm * g.Wm / ((double)tiles_h * tiles_w * 128.0) - 1e-3 * (ph * pw) / 180.0;   // ties: smaller patch
+    if (eff > best) { best = eff; pp.TH = th; pp.TWF = twf; pp.PH = ph; pp.PW = pw; pp.tiles_h = tiles_h; pp.tiles_w = tiles_w; }
+  }
+  if (best < 0.6) return false;
+  pp.dhmin = dhmin; pp.dwmin = dwmin;
+  pp.nct = (g.Cd + tn * 16 - 1) / (tn * 16);
+  pp.lds = pp.PH * pp.PW * slb + 2 * tn * 16 * slb + 160;
+  pp.rcp_nct = 1.0f / (float)pp.nct; pp.rcp_per_img = 1.0f / (float)(pp.tiles_h * pp.tiles_w); pp.rcp_tiles_w = 1.0f / (float)pp.tiles_w;
+  pp.rcp_pw = 1.0f / (float)pp.PW; pp.rcp_twf = 1.0f / (float)pp.TWF;
+  const char* mt = getenv("AST_PCONV_MIN_TILES");
+  const long min_tiles = mt ? atol(mt) : 256;
+  if ((long)g.N * pp.tiles_h * pp.tiles_w * pp.nct < min_tiles) return false;     // under-filled grids keep the K-split plans
+  return pp.lds <= 64 * 1024;
+}
+
+template <typename T, int SLB, int TN>
+int launch_pconv(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t& g, const PconvPlan& pp, int flags,
+                 float* ws, const void* bn_x, const float* bn_scale, const float* bn_shift, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    AST_HIP(hipFuncSetAttribute((const void*)pconv_kernel<T, SLB, 2, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    attr_set = true;
+  }
+  const int tiles = g.N * pp.tiles_h * pp.tiles_w * pp.nct;
+  const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
+  const unsigned wgt_bytes = (unsigned)((size_t)g.Cd * g.wtaps * g.Cs * sizeof(T));
+  // (a persistent variant -- <= 3 workgroups per CU walking their XCD's tiles with the next patch prefetched into
+  // registers -- measured SLOWER, 41 -> 54 us on the 64->64-channel layer: the prefetch registers cost a wave per SIMD,
+  // and what the kernel lacks is overlap between workgroups, not bandwidth)
+  const int grid = (tiles + 7) / 8 * 8;
+  hipLaunchKernelGGL((pconv_kernel<T, SLB, 2, TN>), dim3(grid), dim3(256), pp.lds, s, (const T*)src, (const T*)wgt, bias, (T*)dst,
+                     g, pp, flags, ws, src_bytes, wgt_bytes, (const T*)bn_x, bn_scale, bn_shift);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
 struct IgemmPlan { int bm, bn, kch, nsplit, kt_per_split, depth, kgroups; const void* bn_x; const float* bn_scale; const float* bn_shift; };
 
 IgemmPlan plan_igemm(const ast_gather_t& g, int M, int dtype) {
@@ -1169,6 +1427,10 @@ int check_gather(const ast_gather_t* g, const char* who) {
 extern "C" long ast_igemm_ws_floats(const ast_gather_t* gp, int dtype) {
   if (!gp || check_gather(gp, "ast_igemm_ws_floats")) return -1;
   const int M = gp->N * gp->Hm * gp->Wm;
+  {
+    PconvPlan pp; int slb = 0, tn = 0;
+    if (plan_pconv(*gp, dtype, pp, slb, tn)) return 0;      // the patch kernel never splits K
+  }
   const IgemmPlan p = plan_igemm(*gp, M, dtype);
   return p.nsplit > 1 ? (long)M * gp->Cd : 0;
 }
@@ -1177,6 +1439,13 @@ extern "C" int ast_igemm_plan(const ast_gather_t* gp, int dtype, int* out5) {
   if (!gp || !out5 || check_gather(gp, "ast_igemm_plan")) return -1;
   const IgemmPlan p = plan_igemm(*gp, gp->N * gp->Hm * gp->Wm, dtype);
   out5[0] = p.bm; out5[1] = p.bn; out5[2] = p.kch; out5[3] = p.nsplit; out5[4] = p.kgroups;
+  {
+    PconvPlan pp; int slb = 0, tn = 0;
+    if (plan_pconv(*gp, dtype, pp, slb, tn)) {  // patch kernel: reported as BM = -(tile rows), kch = -(slab bytes)
+      out5[0] = -pp.TH; out5[1] = tn * 16; out5[2] = -slb; out5[3] = 1; out5[4] = 1;
+      return 0;
+    }
+  }
   if (direct_ok(*gp, p, dtype)) {                            // LDS-free narrow-layer kernel: kch = 0 marks it
     out5[0] = 64 * direct_jt(gp->N * gp->Hm * gp->Wm); out5[1] = gp->Cd <= 16 ? 16 : 32; out5[2] = 0;
   }
@@ -1193,6 +1462,20 @@ extern "C" int ast_igemm_bn(const void* src, const void* wgt, const float* bias,
   hipStream_t s = (hipStream_t)stream;
   IgemmPlan p = plan_igemm(g, M, dtype);
   p.bn_x = bn_x; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
+  {
+    PconvPlan pp; int slb = 0, tn = 0;
+    if (plan_pconv(g, dtype, pp, slb, tn)) {
+      if ((flags & 16) && ((flags & 11) || !ws || ws_floats < 64L * g.Cd * 3 || !bn_x || !bn_scale || !bn_shift))
+        AST_FAIL("ast_igemm: fused BatchNorm-backward sums need plain stores, a zeroed [64][Cd][3] table and the layer's x / scale / shift");
+      if ((flags & 8) && ((flags & 3) || !ws || ws_floats < 64L * g.Cd * 2)) AST_FAIL("ast_igemm: fused channel statistics need plain stores and a zeroed [64][Cd][2] table");
+      AST_DISPATCH_T(dtype, {
+        if (slb == 128) { if (tn == 4) return launch_pconv<T, 128, 4>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s);
+                          return launch_pconv<T, 128, 2>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s); }
+        if (tn == 4) return launch_pconv<T, 64, 4>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s);
+        return launch_pconv<T, 64, 2>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s);
+      });
+    }
+  }
   if (flags & 16) {
     if (p.nsplit > 1) AST_FAIL("ast_igemm: fused BatchNorm-backward sums are not available for a split-K plan (check ast_igemm_plan)");
     if ((flags & 11) || !ws || ws_floats < 64L * g.Cd * 3 || !bn_x || !bn_scale || !bn_shift)

@@ -121,6 +121,75 @@ def test_conv2d_fwd_bwd(dtype, cin, cout, k, stride, H, W, N):
     assert rel_err(m.weight_u, sd["weight_u"]) < 1e-4 and rel_err(m.weight_v, sd["weight_v"]) < 1e-4
 
 
+class _env:
+    """os.environ overrides for the duration of a block (libast_hip reads its tuning variables per call)."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update({k: str(v) for k, v in self.kv.items()})
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        return False
+
+
+def _plan(N, H, W, Cs, Cd, k, stride, pad, dtype, transposed=False):
+    import ctypes
+    from ast_amd._lib import dcode, lib
+    g = ops.gather_direct(N, H, W, Cs, Cd, k, stride, pad)[0] if not transposed else transposed
+    out = (ctypes.c_int32 * 5)()
+    assert lib().ast_igemm_plan(g, dcode(dtype), ctypes.byref(out)) == 0
+    return list(out)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,N", [
+    (32, 32, 3, 1, 19, 23, 3),      # 64-byte (bf16) / 128-byte (f32) pixels, tile overhang on both axes
+    (64, 64, 3, 1, 24, 50, 2),      # 128-byte bf16 slab; f32: two slabs
+    (128, 128, 3, 1, 10, 61, 2),    # two channel tiles, two (bf16) / four (f32) slabs
+    (64, 96, 3, 1, 17, 16, 1),      # partial second channel tile
+    (32, 64, 3, 2, 18, 38, 2),      # stride 2: forward on the gathered kernel, the data gradient's parity classes on patches
+    (64, 32, 3, 2, 21, 45, 2),
+])
+def test_conv2d_patch_kernel(dtype, cin, cout, k, stride, H, W, N):
+    """The same checks as test_conv2d_fwd_bwd with the patch-staged kernel forced on small shapes (it is selected by
+    tile count in production), plus a direct comparison of its output with the gathered kernel's."""
+    with _env(AST_PCONV_MIN_TILES=1):
+        ops._ws_cache.clear()
+        if stride == 1:
+            assert _plan(N, H, W, ops.pad8(cin), ops.pad8(cout), k, stride, 1, dtype)[2] < 0      # the patch kernel is what runs
+        test_conv2d_fwd_bwd(dtype, cin, cout, k, stride, H, W, N)
+        config.set_compute_dtype(dtype)
+        torch.manual_seed(1)
+        x = torch.randn(N, H, W, ops.pad8(cin), device=DEV).to(dtype)
+        wgt = (0.1 * torch.randn(ops.pad8(cout), k * k, ops.pad8(cin), device=DEV)).to(dtype)
+        bias = torch.randn(ops.pad8(cout), device=DEV)
+        g, (Ho, Wo) = ops.gather_direct(N, H, W, ops.pad8(cin), ops.pad8(cout), k, stride, 1)
+        outs = []
+        for pc in (1, 0):
+            with _env(AST_PCONV=pc):
+                ops._ws_cache.clear()                        # the plan (and with it the split-K workspace need) changes with the switch
+                y = torch.empty((N, Ho, Wo, ops.pad8(cout)), dtype=dtype, device=DEV)
+                st = torch.zeros(64 * ops.pad8(cout) * 2, device=DEV) if ops.stats_fusable(g, ops.dcode(dtype)) else None
+                ops._igemm(x, wgt, bias, y, g, stats=st)
+                torch.cuda.synchronize()
+                outs.append((y.float().clone(), None if st is None else st.view(64, -1, 2).sum(0).clone()))
+        ops._ws_cache.clear()
+    (y1, s1), (y0, s0) = outs
+    tol = 1e-5 if dtype == torch.float32 else 1e-2          # bf16: the two kernels round different summation orders
+    assert rel_err(y1, y0) < tol
+    if s1 is not None:                                      # fused BatchNorm statistics of the stored values, against the output itself
+        ref = torch.stack([y1.sum(dim=(0, 1, 2)), (y1 * y1).sum(dim=(0, 1, 2))], dim=1)
+        assert rel_err(s1, ref) < 1e-4
+
+
 @pytest.mark.parametrize("R_out,R_in", [(2, 8), (16, 32), (64, 128), (3, 300)])
 def test_rowmix_fwd_bwd(R_out, R_in):
     """ast_rowmix (class prototypes / prototype gather / section means, style_encoder.py:243-253, losses.py:88,142) for

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Time the forward GEMM of the encoder's stride-1 3x3 layers (and optionally their weight gradients) in isolation:
+tools/conv_bench.py [layers=b0c2,b1c2,b2c2,b3c2] [iters=30] [wgrad]   -- one line per layer: us, TFLOP/s."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "audio-style-transfer_amd")); sys.path.insert(0, ROOT)
+import torch
+from ast_amd import ops
+from ast_amd._lib import lib, check, ptr, stream, dcode
+SH = {"b5c2": (16, 5, 10, 512, 512, 3, 1), "b4c2": (16, 9, 19, 512, 512, 3, 1), "b3c2": (16, 18, 38, 256, 256, 3, 1),
+      "b2c2": (16, 36, 75, 128, 128, 3, 1), "b1c2": (16, 72, 150, 64, 64, 3, 1), "b0c2": (16, 144, 299, 32, 32, 3, 1),
+      "b1c1": (16, 144, 299, 32, 64, 3, 2), "b2c1": (16, 72, 150, 64, 128, 3, 2)}
+layers = (sys.argv[1] if len(sys.argv) > 1 else "b0c2,b1c2,b2c2,b3c2").split(",")
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+wgrad = len(sys.argv) > 3 and sys.argv[3] == "wgrad"
+dt = torch.bfloat16
+for name in layers:
+    N, H, W, Cs, Cd, k, st = SH[name]
+    g, (Ho, Wo) = ops.gather_direct(N, H, W, Cs, Cd, k, st, 1)
+    x = torch.randn(N, H, W, Cs, device="cuda").to(dt); w = (0.05 * torch.randn(Cd, k * k, Cs, device="cuda")).to(dt)
+    y = torch.empty(N, Ho, Wo, Cd, device="cuda", dtype=dt)
+    stats = torch.zeros(64 * Cd * 2, device="cuda")
+    dy = torch.randn(N, Ho, Wo, Cd, device="cuda").to(dt); dw = torch.zeros(Cd, k * k, Cs, device="cuda")
+    def run():
+        if wgrad:
+            check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(dw), g, dcode(dt), stream()))
+        else:
+            check(lib().ast_igemm(ptr(x), ptr(w), None, ptr(y), g, dcode(dt), 8, ptr(stats), stats.numel(), stream()))
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    fl = 2.0 * N * Ho * Wo * Cd * k * k * Cs
+    print(f"{name} {'wgrad' if wgrad else 'fwd+stats'} {ops._igemm_config(g, dcode(dt)) if not wgrad else ''}: {us:7.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
