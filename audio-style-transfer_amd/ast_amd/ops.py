@@ -90,7 +90,7 @@ def _igemm_config(g, dt):
     out = (ctypes.c_int32 * 5)()
     check(lib().ast_igemm_plan(g, dt, ctypes.byref(out)), "ast_igemm_plan")
     if out[2] < 0:                                      # patch kernel: (tile rows) x 128 pixels x channels, slab bytes per pixel
-        return f"patch{-out[0]}r,{out[1]}ch,slab{-out[2]}B"
+        return f"patch{-out[0]}r{'(rows,' + str(-out[3]) + 'frag)' if out[3] < 0 else ''},{out[1]}ch,slab{-out[2]}B"
     return f"{out[0]}x{out[1]},k{out[2] * 16}B" + (f",split{out[3]}" if out[3] > 1 else "") + (f",kg{out[4]}" if out[4] > 1 else "")
 
 

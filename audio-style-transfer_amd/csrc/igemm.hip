@@ -983,7 +983,8 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const T* __restrict__ d
 }
 
 bool plan_wgrad_halo(const ast_gather_t& g, int dtype, int nct, int bmw, WHaloPlan& hp) {
-  if (g.ntaps < 2 || g.Cd > 32) return false;          // measured: wins for <= 32 output channels, loses at 64
+  const char* mc = getenv("AST_WGRAD_HALO_MAXCD");
+  if (g.ntaps < 2 || g.Cd > (mc ? atoi(mc) : 32)) return false;          // measured: wins for <= 32 output channels, loses at 64
   const int E = dtype == AST_BF16 ? 8 : 4, ES = dtype == AST_BF16 ? 2 : 4;
   int dhmin = 64, dhmax = -64, dwmin = 64, dwmax = -64;
   for (int t = 0; t < g.ntaps; ++t) {
@@ -1014,7 +1015,8 @@ int launch_wgrad_halo(const void* dy, const void* src, float* dw, const ast_gath
   const int gx = (g.Cd + BMW - 1) / BMW, gy = (g.ntaps * g.Cs + NCT * 16 - 1) / (NCT * 16);
   // every workgroup adds its whole dW tile into the same few KB: fewer workgroups = less same-address atomic
   // contention; only the largest pixel counts need more than one workgroup per CU (sweep in profiles/r01)
-  const int wg_target = (long)g.N * g.Hm * g.Wm >= 1500000 ? 768 : 256;
+  const char* wt = getenv("AST_WGRAD_WG_TARGET");
+  const int wg_target = wt ? atoi(wt) : ((long)g.N * g.Hm * g.Wm >= 1500000 ? 768 : 256);
   const int gz = std::max(1, std::min(hp.ntiles, wg_target / (gx * gy)));
   const unsigned dy_bytes = (unsigned)((size_t)g.N * g.Hm * g.Wm * g.Cd * sizeof(T));
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
@@ -1044,7 +1046,7 @@ int launch_wgrad_halo(const void* dy, const void* src, float* dw, const ast_gath
 // fragment base pixel (brute-forced over all bases), which the per-tap shifts need.
 // ---------------------------------------------------------------------------
 constexpr int PC_MAXPL = 8;          // patch chunks (16 B) per thread
-struct PconvPlan { int TH, TWF, PH, PW, dhmin, dwmin, tiles_h, tiles_w, nct, lds; float rcp_nct, rcp_per_img, rcp_tiles_w, rcp_pw, rcp_twf; };
+struct PconvPlan { int TH, TWF, PH, PW, dhmin, dwmin, tiles_h, tiles_w, nct, lds, rows, tm; float rcp_nct, rcp_per_img, rcp_tiles_w, rcp_pw, rcp_twf; };
 
 template <int SLB> __device__ __forceinline__ int pc_h(int p) { return SLB == 128 ? (p & 7) : ((p >> 1) & 3); }
 
@@ -1076,7 +1078,7 @@ __global__ __launch_bounds__(256) void pconv_kernel(const T* __restrict__ src, c
   const int st = fdiv(tix, pp.nct, pp.rcp_nct), ct = tix - st * pp.nct;      // channel tiles of one spatial tile are neighbours (same patch in L2)
   const int n = fdiv(st, per_img, pp.rcp_per_img), r = st - n * per_img;
   const int th = fdiv(r, pp.tiles_w, pp.rcp_tiles_w), tw = r - th * pp.tiles_w;
-  const int TWP = pp.TWF * 16;
+  const int TWP = pp.rows ? g.Wm : pp.TWF * 16;
   const int hm0 = th * pp.TH, wm0 = tw * TWP;
   const int bn0 = ct * BN;
   const int hs_org = hm0 + g.oh + pp.dhmin, ws_org = wm0 + g.ow + pp.dwmin;      // stride-1 gathers only (plan_pconv)
@@ -1129,12 +1131,24 @@ __global__ __launch_bounds__(256) void pconv_kernel(const T* __restrict__ src, c
   int aoff[TN];                                   // weight rows i*16 + fr: H(row) = H(fr)
 #pragma unroll
   for (int i = 0; i < TN; ++i) aoff[i] = (i * 16 + fr) * SLB + ((fq ^ pc_h<SLB>(fr)) << 4);
+  // Lane -> output pixel of fragment f.  2-D tiles: fragment = 16 consecutive pixels of tile row f / TWF.  Row-block tiles
+  // (pp.rows: TH full-width rows of a narrow image): the tile's pixels in raster order, 16 per fragment (a fragment may
+  // straddle a row end; its patch pixels then jump by the halo width: a 2-way LDS conflict on that read, no more).
+  auto lane_pixel = [&](int j, int& ty, int& tx) __attribute__((always_inline)) {
+    const int f = __builtin_amdgcn_readfirstlane(wave) * TM + j;      // wave-uniform: scalar arithmetic
+    if (pp.rows) {
+      const int q = f * 16 + fr;
+      ty = fdiv(q, g.Wm, pp.rcp_twf); tx = q - ty * g.Wm;             // rcp_twf = 1 / Wm in this mode
+    } else {
+      ty = fdiv(f, pp.TWF, pp.rcp_twf); tx = (f - ty * pp.TWF) * 16 + fr;
+    }
+  };
   int pb[TM];                                     // patch pixel of this lane's output pixel (before the tap offset)
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
-    const int f = __builtin_amdgcn_readfirstlane(wave) * TM + j;      // wave-uniform: scalar arithmetic
-    const int ty = fdiv(f, pp.TWF, pp.rcp_twf), tx = (f - ty * pp.TWF) * 16 + fr;
-    pb[j] = ty * pp.PW + tx;
+    int ty, tx;
+    lane_pixel(j, ty, tx);
+    pb[j] = ty < pp.TH ? ty * pp.PW + tx : 0;     // lanes past the tile read a valid address; their results are dropped
   }
 
   f32x4 acc[TN][TM];
@@ -1212,10 +1226,10 @@ __global__ __launch_bounds__(256) void pconv_kernel(const T* __restrict__ src, c
     for (int q = 0; q < 4; ++q) { st1[i][q] = 0.f; st2[i][q] = 0.f; }
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
-    const int f = __builtin_amdgcn_readfirstlane(wave) * TM + j;
-    const int ty = fdiv(f, pp.TWF, pp.rcp_twf), tx = (f - ty * pp.TWF) * 16 + fr;
+    int ty, tx;
+    lane_pixel(j, ty, tx);
     const int hm = hm0 + ty, wq = wm0 + tx;
-    if (hm >= g.Hm || wq >= g.Wm) continue;
+    if (ty >= pp.TH || hm >= g.Hm || wq >= g.Wm) continue;
     f32x4 col[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) col[i] = acc[i][j];
@@ -1240,33 +1254,46 @@ bool plan_pconv(const ast_gather_t& g, int dtype, PconvPlan& pp, int& slb, int& 
     dhmin = std::min(dhmin, dh); dhmax = std::max(dhmax, dh); dwmin = std::min(dwmin, dw); dwmax = std::max(dwmax, dw);
   }
   const int cpp = slb / 16;
+  const int max_px = 256 * PC_MAXPL / cpp;                        // patch pixels a workgroup's loader covers
   double best = 0.0;
+  pp.rows = 0; pp.tm = 2;
   for (int twf = 1; twf <= 8; twf *= 2) {                         // 8 fragments per workgroup: 8x16, 4x32, 2x64, 1x128 pixels
     const int th = 8 / twf, twp = twf * 16;
     const int ph = th + (dhmax - dhmin), pw = twp + (dwmax - dwmin);
-    if (ph * pw * cpp > 256 * PC_MAXPL) continue;
+    if (ph * pw > max_px) continue;
     const int tiles_h = (g.Hm + th - 1) / th, tiles_w = (g.Wm + twp - 1) / twp;
     const double eff = (double)g.Hm * g.Wm / ((double)tiles_h * tiles_w * 128.0) - 1e-3 * (ph * pw) / 180.0;   // ties: smaller patch
     if (eff > best) { best = eff; pp.TH = th; pp.TWF = twf; pp.PH = ph; pp.PW = pw; pp.tiles_h = tiles_h; pp.tiles_w = tiles_w; }
   }
+  // narrow images (the deep layers: 18x38, 9x19 pixels): TH full-width rows per workgroup, 8 or 12 fragments
+  for (int nf = 8; nf <= 12; nf += 4)
+    for (int th = 1; th * g.Wm <= nf * 16 && th <= g.Hm; ++th) {
+      const int ph = th + (dhmax - dhmin), pw = g.Wm + (dwmax - dwmin);
+      if (ph * pw > max_px) continue;
+      const int tiles_h = (g.Hm + th - 1) / th;
+      const double eff = (double)g.Hm * g.Wm / ((double)tiles_h * nf * 16.0) - 1e-3 * (ph * pw) / 180.0 - 0.02;   // prefer 2-D tiles on a tie
+      if (eff > best) { best = eff; pp.rows = 1; pp.tm = nf / 4; pp.TH = th; pp.TWF = 1; pp.PH = ph; pp.PW = pw; pp.tiles_h = tiles_h; pp.tiles_w = 1; }
+    }
   if (best < 0.6) return false;
   pp.dhmin = dhmin; pp.dwmin = dwmin;
+  const long spatial = (long)g.N * pp.tiles_h * pp.tiles_w;
+  if (tn == 4 && spatial * ((g.Cd + 63) / 64) < 200) tn = 2;      // few tiles: 32-channel tiles double the workgroups
   pp.nct = (g.Cd + tn * 16 - 1) / (tn * 16);
   pp.lds = pp.PH * pp.PW * slb + 2 * tn * 16 * slb + 160;
   pp.rcp_nct = 1.0f / (float)pp.nct; pp.rcp_per_img = 1.0f / (float)(pp.tiles_h * pp.tiles_w); pp.rcp_tiles_w = 1.0f / (float)pp.tiles_w;
-  pp.rcp_pw = 1.0f / (float)pp.PW; pp.rcp_twf = 1.0f / (float)pp.TWF;
+  pp.rcp_pw = 1.0f / (float)pp.PW; pp.rcp_twf = 1.0f / (float)(pp.rows ? g.Wm : pp.TWF);
   const char* mt = getenv("AST_PCONV_MIN_TILES");
-  const long min_tiles = mt ? atol(mt) : 256;
-  if ((long)g.N * pp.tiles_h * pp.tiles_w * pp.nct < min_tiles) return false;     // under-filled grids keep the K-split plans
+  const long min_tiles = mt ? atol(mt) : 192;
+  if (spatial * pp.nct < min_tiles) return false;                 // under-filled grids keep the K-split plans
   return pp.lds <= 64 * 1024;
 }
 
-template <typename T, int SLB, int TN>
+template <typename T, int SLB, int TM, int TN>
 int launch_pconv(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t& g, const PconvPlan& pp, int flags,
                  float* ws, const void* bn_x, const float* bn_scale, const float* bn_shift, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    AST_HIP(hipFuncSetAttribute((const void*)pconv_kernel<T, SLB, 2, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    AST_HIP(hipFuncSetAttribute((const void*)pconv_kernel<T, SLB, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     attr_set = true;
   }
   const int tiles = g.N * pp.tiles_h * pp.tiles_w * pp.nct;
@@ -1276,7 +1303,7 @@ int launch_pconv(const void* src, const void* wgt, const float* bias, void* dst,
   // registers -- measured SLOWER, 41 -> 54 us on the 64->64-channel layer: the prefetch registers cost a wave per SIMD,
   // and what the kernel lacks is overlap between workgroups, not bandwidth)
   const int grid = (tiles + 7) / 8 * 8;
-  hipLaunchKernelGGL((pconv_kernel<T, SLB, 2, TN>), dim3(grid), dim3(256), pp.lds, s, (const T*)src, (const T*)wgt, bias, (T*)dst,
+  hipLaunchKernelGGL((pconv_kernel<T, SLB, TM, TN>), dim3(grid), dim3(256), pp.lds, s, (const T*)src, (const T*)wgt, bias, (T*)dst,
                      g, pp, flags, ws, src_bytes, wgt_bytes, (const T*)bn_x, bn_scale, bn_shift);
   AST_CHECK_LAUNCH();
   return 0;
@@ -1442,7 +1469,7 @@ extern "C" int ast_igemm_plan(const ast_gather_t* gp, int dtype, int* out5) {
   {
     PconvPlan pp; int slb = 0, tn = 0;
     if (plan_pconv(*gp, dtype, pp, slb, tn)) {  // patch kernel: reported as BM = -(tile rows), kch = -(slab bytes)
-      out5[0] = -pp.TH; out5[1] = tn * 16; out5[2] = -slb; out5[3] = 1; out5[4] = 1;
+      out5[0] = -pp.TH; out5[1] = tn * 16; out5[2] = -slb; out5[3] = pp.rows ? -(pp.tm * 4) : 1; out5[4] = 1;
       return 0;
     }
   }
@@ -1468,23 +1495,15 @@ extern "C" int ast_igemm_bn(const void* src, const void* wgt, const float* bias,
       if ((flags & 16) && ((flags & 11) || !ws || ws_floats < 64L * g.Cd * 3 || !bn_x || !bn_scale || !bn_shift))
         AST_FAIL("ast_igemm: fused BatchNorm-backward sums need plain stores, a zeroed [64][Cd][3] table and the layer's x / scale / shift");
       if ((flags & 8) && ((flags & 3) || !ws || ws_floats < 64L * g.Cd * 2)) AST_FAIL("ast_igemm: fused channel statistics need plain stores and a zeroed [64][Cd][2] table");
+#define AST_PC(S_, M_, N_) return launch_pconv<T, S_, M_, N_>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s)
       AST_DISPATCH_T(dtype, {
-        if (slb == 128) { if (tn == 4) return launch_pconv<T, 128, 4>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s);
-                          return launch_pconv<T, 128, 2>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s); }
-        if (tn == 4) return launch_pconv<T, 64, 4>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s);
-        return launch_pconv<T, 64, 2>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s);
+        if (slb == 128 && pp.tm == 2) { if (tn == 4) AST_PC(128, 2, 4); AST_PC(128, 2, 2); }
+        if (slb == 128) { if (tn == 4) AST_PC(128, 3, 4); AST_PC(128, 3, 2); }
+        if (pp.tm == 2) { if (tn == 4) AST_PC(64, 2, 4); AST_PC(64, 2, 2); }
+        if (tn == 4) AST_PC(64, 3, 4); AST_PC(64, 3, 2);
       });
+#undef AST_PC
     }
-  }
-  if (flags & 16) {
-    if (p.nsplit > 1) AST_FAIL("ast_igemm: fused BatchNorm-backward sums are not available for a split-K plan (check ast_igemm_plan)");
-    if ((flags & 11) || !ws || ws_floats < 64L * g.Cd * 3 || !bn_x || !bn_scale || !bn_shift)
-      AST_FAIL("ast_igemm: fused BatchNorm-backward sums need plain stores, a zeroed [64][Cd][3] table and the layer's x / scale / shift");
-  }
-  if (p.nsplit > 1 && (!ws || ws_floats < (long)M * g.Cd)) AST_FAIL("ast_igemm: split-K needs a workspace of %ld floats (ast_igemm_ws_floats)", (long)M * g.Cd);
-  if (flags & 8) {
-    if (p.nsplit > 1) AST_FAIL("ast_igemm: fused channel statistics are not available for a split-K plan (check ast_igemm_plan)");
-    if ((flags & 3) || !ws || ws_floats < 64L * g.Cd * 2) AST_FAIL("ast_igemm: fused channel statistics need plain stores and a zeroed [64][Cd][2] table");
   }
   if (direct_ok(g, p, dtype)) { AST_DISPATCH_T(dtype, { return dispatch_direct<T>(src, wgt, bias, dst, g, M, flags, ws, p, s); }); }
 #define AST_IG(BM_, BN_, WM_, WN_, K_) return launch_igemm<T, BM_, BN_, WM_, WN_, K_, 2, 1>(src, wgt, bias, dst, g, M, flags, ws, p, s)

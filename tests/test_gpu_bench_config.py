@@ -75,7 +75,9 @@ CASES = {
     # Measured at this configuration (GPUTEST log line "[bench-config parity] bf16"): rec 1.4e-4, nce 6e-5, adv_g 2e-4,
     # adv_d 3.8e-4, total 1.9e-3 (it contains the margin term), hsic 3.2e-2 (a 7e-3-sized statistic of embedding
     # differences); gradients style 0.25, content 0.053, decoder 0.055.
-    "bf16": (torch.bfloat16, {"*": 1e-3, "total": 4e-3, "hsic": 6.4e-2}, {"style": 0.5, "content": 0.11, "decoder": 0.11}),
+    # Three runs on different boxes gave hsic 2.9 / 3.2 / 3.4e-2 and total 1.4e-4 .. 1.9e-3 (f32 atomic order differs from
+    # run to run and bf16 rounding amplifies it), one run exceeded a 2x bound: the bounds are 3x the largest value seen.
+    "bf16": (torch.bfloat16, {"*": 2e-3, "total": 6e-3, "hsic": 0.1}, {"style": 0.6, "content": 0.16, "decoder": 0.16}),
 }
 
 

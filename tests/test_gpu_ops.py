@@ -155,6 +155,8 @@ def _plan(N, H, W, Cs, Cd, k, stride, pad, dtype, transposed=False):
     (64, 64, 3, 1, 24, 50, 2),      # 128-byte bf16 slab; f32: two slabs
     (128, 128, 3, 1, 10, 61, 2),    # two channel tiles, two (bf16) / four (f32) slabs
     (64, 96, 3, 1, 17, 16, 1),      # partial second channel tile
+    (256, 256, 3, 1, 18, 38, 2),    # narrow image: row-block tiles (3 full rows, fragments straddle row ends), 4 slabs
+    (128, 64, 3, 1, 9, 19, 3),      # whole 9x19 image per workgroup, 12 fragments
     (32, 64, 3, 2, 18, 38, 2),      # stride 2: forward on the gathered kernel, the data gradient's parity classes on patches
     (64, 32, 3, 2, 21, 45, 2),
 ])
