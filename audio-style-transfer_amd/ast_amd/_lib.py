@@ -112,9 +112,63 @@ EXPORTS = tuple(_SIGS) + ("ast_last_error",)
 _lib = None
 
 
+# ---- optional per-call profiling (bench.py's roofline.kernels[]): when PROFILE_CALLS is a list, every C-ABI call of the
+# functions named in CALL_BYTES is bracketed by device events on the current stream and recorded as
+# (name, algorithmic bytes, start event, end event).  Off (None) in normal operation: lib() returns the raw CDLL.
+PROFILE_CALLS = None
+NEXT_BYTES = None          # set by a caller whose byte count is not derivable from the arguments (weight pack / flush)
+
+
+def _es(dtype_code):
+    return 2 if dtype_code == BF16 else 4
+
+
+CALL_BYTES = {
+    # BatchNorm/InstanceNorm apply (+ReLU, + ResBlock add): read x (+ shortcut), write y
+    "ast_affine_act": lambda a: a[7] * a[8] * a[9] * _es(a[11]) * (2 + (1 if a[3] else 0)),
+    # norm backward apply: read dy, x (+ shortcut input), write dx (+ shortcut gradient)
+    "ast_norm_bwd_apply_pre": lambda a: a[8] * a[9] * a[10] * _es(a[12]) * (3 + (2 if a[3] else 0)),
+    "ast_norm_bwd_sums_pre": lambda a: a[5] * a[6] * a[7] * _es(a[9]) * (2 + (1 if a[3] else 0)),
+    "ast_chan_stats": lambda a: a[2] * a[3] * a[4] * _es(a[5]),
+    # compute_comprehensive_loss: read output and target, write the gradient (f32)
+    "ast_recon_loss": lambda a: 3 * 4 * a[3] * a[4] * 2 * a[5] * a[6],
+    "ast_adam": lambda a: 7 * 4 * a[4],                    # read p, g, m, v; write p, m, v
+    "ast_sumsq": lambda a: 4 * a[1],
+    "ast_weights_prepare_t": None,                         # bytes from NEXT_BYTES (WeightBank)
+    "ast_weight_grads_flush_t": None,
+    "ast_nchw_to_nhwc": lambda a: a[2] * a[4] * a[5] * (a[3] * 4 + a[9] * _es(a[10])),
+    "ast_bilinear_fwd": lambda a: a[0] and a[2] * (a[5] * a[6] * a[4] * _es(a[9]) + a[3] * a[7] * a[8] * 4),
+}
+
+
+class _ProfiledLib:
+    def __init__(self, raw):
+        self._raw = raw
+
+    def __getattr__(self, name):
+        fn = getattr(self._raw, name)
+        if name not in CALL_BYTES:
+            return fn
+
+        def wrapped(*args):
+            global NEXT_BYTES
+            f = CALL_BYTES[name]
+            nbytes = NEXT_BYTES if f is None else f(args)
+            NEXT_BYTES = None
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            PROFILE_CALLS.append((name, float(nbytes or 0), e0, e1))
+            return rc
+        return wrapped
+
+
 def lib():
     """The loaded library; raises (never falls back) if it has not been built."""
     global _lib
+    if _lib is not None and PROFILE_CALLS is not None:
+        return _ProfiledLib(_lib)
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(

@@ -115,3 +115,42 @@ def get_dataloader(piano_dir, violin_dir, batch_size=8, shuffle=True, stats_path
         batch_size = batch_size - 1
     dataset = DualInstrumentDataset(piano_dir, violin_dir, stats_path, use_separate_stats, **dataset_kw)
     return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, collate_fn=custom_collate_fn, drop_last=True)
+
+
+# ---- variable-length clips (BASELINE configs[4]) -------------------------------------------------------------------
+def sections_for_samples(n_samples: int) -> int:
+    """Number of 287-frame sections get_overlap_windows makes of a clip of n_samples at hop 256 (utilityFunctions.py:246-262:
+    2-3 s -> 1, 4-6 s -> 2, 7-8 s -> 3, 10 s -> 4; a tail shorter than half a window is dropped)."""
+    return len(U.section_starts(1 + n_samples // 256))
+
+
+class LengthBucketSampler(torch.utils.data.Sampler):
+    """Batch sampler for clips of mixed length.  custom_collate_fn stacks the items of a batch (dataloader.py:136-142), so all
+    of them must have the same number of sections S -- and the batched front end wants equal sample counts -- hence batches
+    are drawn from one LENGTH bucket at a time (every bucket has one S; zero-padding a short clip to a longer bucket would
+    move the STFT's reflect padding away from the clip's true end and change its last frames).  Yields lists of item indices;
+    incomplete batches are dropped, as get_dataloader does."""
+
+    def __init__(self, n_samples_per_item, batch_size: int, shuffle: bool = True, seed: int = 0):
+        self.batch_size, self.shuffle, self.seed, self.epoch = int(batch_size), shuffle, seed, 0
+        self.buckets = {}
+        for i, n in enumerate(n_samples_per_item):
+            self.buckets.setdefault(int(n), []).append(i)
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        batches = []
+        for n in sorted(self.buckets):
+            idx = self.buckets[n]
+            if self.shuffle:
+                idx = [idx[j] for j in torch.randperm(len(idx), generator=g).tolist()]
+            batches += [idx[k:k + self.batch_size] for k in range(0, len(idx) - self.batch_size + 1, self.batch_size)]
+        if self.shuffle:
+            batches = [batches[j] for j in torch.randperm(len(batches), generator=g).tolist()]
+        return iter(batches)
+
+    def __len__(self):
+        return sum(len(v) // self.batch_size for v in self.buckets.values())

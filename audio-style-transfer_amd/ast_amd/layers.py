@@ -131,6 +131,9 @@ class WeightBank:
         if self._keys.get(training) != self._signature(training):
             self._build(training)
         d = self.d_train if training else self.d_eval
+        from . import _lib as _L
+        if _L.PROFILE_CALLS is not None:       # algorithmic bytes of the pack: read the f32 masters, write both packed images
+            _L.NEXT_BYTES = sum(e.Co * e.Ci * e.KK * 4 + 2 * e.wf.numel() * e.wf.element_size() for e in self.entries)
         check(lib().ast_weights_prepare_t(ptr(d), ptr(self.d_dtypes), len(self.entries), self.max_co, self.max_cols,
                                           ptr(self.d_tiles), self.ntiles, stream()), "ast_weights_prepare_t")
 
@@ -149,6 +152,9 @@ class WeightBank:
         self._flush_pending = False
         if self._conv_dirty:
             self._conv_dirty = False
+            from . import _lib as _L
+            if _L.PROFILE_CALLS is not None:   # read the packed f32 staging + the master (spectral-norm term), add into the gradient
+                _L.NEXT_BYTES = sum((e.dwp.numel() * 4 if e.dwp is not None else 0) + 3 * e.Co * e.Ci * e.KK * 4 for e in self.entries if e.dwp is not None)
             check(lib().ast_weight_grads_flush_t(ptr(self.d_train), ptr(self.d_tiles), self.ntiles, stream()),
                   "ast_weight_grads_flush_t")
         if self._lin_deferred:
@@ -349,3 +355,32 @@ class DecoderLayer:
         h = ops.ffn(h.reshape(B * L, d), self.ff1, self.ff2, l.dropout.p, training)
         x, _ = ops.add_drop_ln(x, h.view(B, L, d), None, l.dropout3.p, training)
         return x
+
+    # ---- incremental (KV-cached) decoding: eval / no-grad only -----------------------------------
+    def memory_kv(self, memory):
+        """K | V projections of the cross-attention memory, (B*Lm, 2d): computed once per generated sequence."""
+        B, Lm, d = memory.shape
+        return linear(memory.reshape(B * Lm, d), self.ca.kv), Lm
+
+    def step(self, x_t, kv_self, mem_kv):
+        """One new token x_t (B,1,d) through the layer.  kv_self: cached (B, t, 2d) K|V of the earlier tokens of THIS layer (or
+        None); returns (y_t, kv_self grown by one).  Causality makes the earlier tokens' K/V independent of later ones, so
+        this equals row t of the full-sequence layer (new_decoder.py:294-314 recomputes all rows every step)."""
+        l = self.l
+        B, _, d = x_t.shape
+        dh = d // self.sa.h
+        h = layer_norm(x_t, l.norm1).reshape(B, d)
+        qkv = linear(h, self.sa.qkv)                                   # (B, 3d): q | k | v of the new token
+        new_kv = qkv[:, d:].reshape(B, 1, 2 * d)
+        kv_self = new_kv if kv_self is None else torch.cat([kv_self, new_kv], dim=1)
+        t1 = kv_self.shape[1]
+        q = qkv[:, :d].contiguous()
+        o = ops.AttnCoreFn.apply(q, kv_self.reshape(B * t1, 2 * d), B, self.sa.h, 1, t1, dh, 0, d, False, 0.0)
+        x = x_t.reshape(B, d) + linear(o, self.sa.out)
+        h = layer_norm(x, l.norm2)
+        kvm, Lm = mem_kv
+        o = ops.AttnCoreFn.apply(linear(h, self.ca.q), kvm, B, self.ca.h, 1, Lm, dh, 0, d, False, 0.0)
+        x = x + linear(o, self.ca.out)
+        h = layer_norm(x, l.norm3)
+        x = x + linear(linear(h, self.ff1, relu=True), self.ff2)
+        return x.view(B, 1, d), kv_self

@@ -152,10 +152,32 @@ class Decoder(nn.Module):
         self._prepare()
         return self._training_pass(y, memory)
 
+    # How forward_inference walks the sequence: "recompute" = the reference's loop (new_decoder.py:294-314: the whole
+    # stack over all tokens generated so far, every step); "kv_cache" = one new token per step against cached per-layer
+    # K/V (identical results: the layers are causal).  Class attribute so callers and tests can switch it.
+    decode_mode = "recompute"
+
+    def _inference_pass_cached(self, memory, target_length):
+        B, d = memory.size(0), self.d_model
+        mem_kv = [lyr.memory_kv(memory) for lyr in self._layers]
+        caches = [None] * len(self._layers)
+        tok = self.start_token.expand(B, -1, -1)
+        pe = self.pos_encoding.pe
+        outs = []
+        for t in range(target_length):
+            x = tok + pe[:, t:t + 1]
+            for i, lyr in enumerate(self._layers):
+                x, caches[i] = lyr.step(x, caches[i], mem_kv[i])
+            outs.append(x)
+            tok = x
+        return self._generate(torch.cat(outs, dim=1))
+
     def _inference_pass(self, memory, target_length=None):
         B = memory.size(0)
         if target_length is None:
             target_length = memory.size(1) // 2
+        if self.decode_mode == "kv_cache" and not torch.is_grad_enabled():
+            return self._inference_pass_cached(memory, target_length)
         seq = self.start_token.expand(B, -1, -1)
         outs = []
         for _ in range(target_length):

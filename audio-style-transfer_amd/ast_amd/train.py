@@ -392,10 +392,13 @@ class Trainer:
         read the new values on their next replay.  New shapes get new buffers, and the graph cache key (which holds
         the buffer addresses) makes step() capture again."""
         def own(slot, t):
+            # one persistent buffer per (slot, shape): a stream of mixed clip lengths (BASELINE configs[4]) alternates between
+            # a few waveform shapes, and each keeps its buffers -- and with them its captured graph -- across the switches
             t = t.detach()
-            cur = self._fe_bufs.get(slot)
-            if cur is None or cur.shape != t.shape or cur.dtype != t.dtype or cur.device != t.device:
-                cur = self._fe_bufs[slot] = t.contiguous().clone()
+            key = (slot, tuple(t.shape), t.dtype, str(t.device))
+            cur = self._fe_bufs.get(key)
+            if cur is None:
+                cur = self._fe_bufs[key] = t.contiguous().clone()
             elif cur.data_ptr() != t.data_ptr():
                 cur.copy_(t)
             return cur

@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "audio-style-transfer_amd"))
 sys.path.insert(0, ROOT)
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -27,53 +28,78 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # dense MFMA peaks, MI355X_MIC
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(sample_B=2, S=2, steps=2):
-    """The oracle's restatement of the same step (D phase + G phase + clip + Adam) in fp32 on the host
-    cores, on a bounded sample (B=2 instead of 8: per-clip cost is batch-linear on CPU)."""
-    from oracle import ast_oracle as O
-    from oracle import layout as OL
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(B=8, S=2, warm=3, timed=10, budget_s=75.0):
+    """the oracle's restatement of the SAME step (D phase + G phase + clip + Adam, dropout on) in fp32 on the
+    host cores at the benchmarked batch (B=8, S=2), 3 warm-up + 10 timed steps, median; and the front-end oracle
+    (STFT + CQT + z-score + sectioning of the B clips), so the rate is quoted with and without it.  Bounded: stops timing
+    early when the budget is spent (the number of steps actually timed is reported)."""
+    from oracle import cqt_oracle as CO
+    from oracle import frontend_oracle as FO
     from oracle import seeded_params as sp
+    from oracle.train_step import OracleTrainer
     # the GPU box gives one job a 16-core share whatever os.cpu_count() says: more threads only thrash
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
-    sds = {t: OL.seeded_model_state(t) for t in ("style", "content", "decoder", "disc")}
-    gparams = [v for t in ("style", "content", "decoder") for v in sds[t].values() if v.requires_grad]
-    dparams = [v for v in sds["disc"].values() if v.requires_grad]
-    og, od = torch.optim.Adam(gparams, lr=1e-4), torch.optim.Adam(dparams, lr=1e-4)
-    cfg = O.Cfg(training=True, p_drop=0.1)
-    x = sp.seeded_input(sample_B, S)
-    labels = sp.balanced_labels(sample_B)
-    y = x[..., :513]
-    times = []
-    for it in range(steps + 1):
+    ot = OracleTrainer(p_drop=0.1)
+    x, labels = sp.seeded_input(B, S), sp.balanced_labels(B)
+    times, t_start = [], time.perf_counter()
+    for it in range(warm + timed):
         t0 = time.perf_counter()
-        style, cls = O.style_encoder_forward(sds["style"], x, labels, cfg)
-        content = O.content_encoder_forward(sds["content"], x, cfg)
-        od.zero_grad()
-        d_loss, _ = O.adversarial_loss(sds["disc"], style.detach(), cls.detach(), content.detach(), labels, True)
-        d_loss.backward()
-        torch.nn.utils.clip_grad_norm_(dparams, 1.0)
-        od.step()
-        og.zero_grad()
-        out = O.decoder_forward(sds["decoder"], content, cls[labels], cfg, y=y)
-        total = (O.comprehensive_loss(out, y)["total_loss"] + O.infonce_loss(style, labels) + O.margin_loss(cls)
-                 + O.disentanglement_loss(style, content.mean(1))
-                 + O.adversarial_loss(sds["disc"], style, cls, content, labels, False)[1])
-        total.backward()
-        torch.nn.utils.clip_grad_norm_(gparams, 1.0)
-        og.step()
-        if it > 0:
-            times.append(time.perf_counter() - t0)
-        print(f"[cpu_baseline] step {it}: {time.perf_counter() - t0:.2f} s", file=sys.stderr, flush=True)
-    t = sorted(times)[len(times) // 2]
-    return {"value": sample_B * CLIP_SECONDS / t, "unit": "audio-seconds/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fp32 step (D+G phases, clip, Adam; STFT/CQT front end NOT included, the GPU step includes it), B={sample_B} S={S}, median of {steps} steps after 1 warm-up, {t:.2f} s/step"}
+        ot.step(x, labels)
+        dt = time.perf_counter() - t0
+        if it >= warm:
+            times.append(dt)
+        print(f"[cpu_baseline] step {it}: {dt:.2f} s", file=sys.stderr, flush=True)
+        if time.perf_counter() - t_start > budget_s and len(times) >= 3:
+            break
+    t_med, t_min = sorted(times)[len(times) // 2], min(times)
+    # front end of the same B clips (numpy, one thread: librosa's CQT recursion restated step by step)
+    waves = [FO.synth_waveform(i, "piano" if i < B // 2 else "violin", seconds=CLIP_SECONDS) for i in range(B)]
+    fe = []
+    for rep in range(2):
+        t0 = time.perf_counter()
+        for w in waves:
+            spec = np.concatenate([FO.stft(w), CO.get_cqt(w)], axis=2)
+            FO.overlap_windows(spec)
+        fe.append(time.perf_counter() - t0)
+    t_fe = min(fe)
+    print(f"[cpu_baseline] front end of {B} clips: {t_fe:.2f} s", file=sys.stderr, flush=True)
+    return {"value": B * CLIP_SECONDS / (t_med + t_fe), "unit": "audio-seconds/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": _cpu_model(), "value_model_only": B * CLIP_SECONDS / t_med, "s_per_step_median": t_med, "s_per_step_min": t_min,
+            "s_front_end": t_fe, "steps_timed": len(times),
+            "sample": f"oracle fp32 step (D+G phases, clip, Adam, dropout 0.1) at the benchmarked B={B} S={S}: {warm} warm-up + {len(times)} timed steps, "
+                      f"median {t_med:.2f} s (min {t_min:.2f}); + oracle STFT/CQT front end of the {B} clips {t_fe:.2f} s (single-thread numpy); "
+                      "`value` includes the front end as the GPU step does, `value_model_only` does not"}
+
+
+def _newest_traffic_file():
+    """profiles/r<NN>/*pmc_traffic*.json of the highest round (written by tools/pmc_traffic.sh + .py from rocprofv3 --pmc passes)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_traffic*.json")):
+        m = re.search(r"profiles[/\\]r(\d+)", f)
+        key = (int(m.group(1)) if m else -1, os.path.getmtime(f))
+        if best is None or key > best[0]:
+            best = (key, f)
+    return best[1] if best else None
 
 
 def kernel_roofline(trainer, x, labels, dtype_name):
-    """Eager (un-graphed) steps with device events around every GEMM launch; aggregates per kernel
-    configuration and reports the one with the largest total time."""
-    from ast_amd import ops
-    ops.PROFILE = []
+    """Eager (un-graphed) steps with device events around every GEMM launch (ops.PROFILE) and around the HBM-bound kernel
+    families (_lib.PROFILE_CALLS); aggregates per kernel configuration.  `roofline` = the GEMM configuration with the
+    largest total time; `roofline.kernels[]` = the streaming kernels against the 8 TB/s HBM peak."""
+    from ast_amd import _lib, ops
+    ops.PROFILE, _lib.PROFILE_CALLS = [], []
     was = trainer.cfg.use_graph
     trainer.cfg.use_graph = False
     nsteps = 2
@@ -82,6 +108,7 @@ def kernel_roofline(trainer, x, labels, dtype_name):
     torch.cuda.synchronize()
     trainer.cfg.use_graph = was
     recs, ops.PROFILE = ops.PROFILE, None
+    calls, _lib.PROFILE_CALLS = _lib.PROFILE_CALLS, None
     agg = {}
     for name, flops, nbytes, e0, e1 in recs:
         a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
@@ -98,26 +125,46 @@ def kernel_roofline(trainer, x, labels, dtype_name):
     else:
         roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
     traffic, traffic_src = None, None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "d_pmc_traffic.json")
-    if os.path.exists(pmc):
+    pmc = _newest_traffic_file()
+    if pmc:
         # HBM bytes per launch from rocprofv3 PMC passes over this same workload (tools/pmc_traffic.sh + .py: separate
         # FETCH_SIZE / WRITE_SIZE runs, KiB units, gfx950 x2 fetch correction); counters cannot be read in-process
-        rec = json.load(open(pmc)).get(name)
+        table = json.load(open(pmc))
+        meta = table.get("_meta", {})
+        rec = table.get(name)
+        rel = os.path.relpath(pmc, ROOT)
         if rec:
-            traffic, traffic_src = rec["traffic_bytes"], "profiles/r01/d_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB->bytes, mean per launch)"
+            traffic = rec["traffic_bytes"]
+            traffic_src = f"{rel} (git {meta.get('git_head', 'unknown')}; 2*FETCH_SIZE + WRITE_SIZE, KiB->bytes, mean per launch)"
+        else:
+            traffic_src = f"{rel} holds no entry for kernel '{name}' (kernel names changed since it was collected: re-run tools/pmc_traffic.sh)"
+            print(f"warning: {traffic_src}", file=sys.stderr)
     roof.update({"traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "kernel": name, "launches_per_step": cnt // nsteps, "avg_launch_us": t / cnt * 1e6,
                  "algorithmic_flops_per_launch": fl / cnt, "algorithmic_bytes_per_launch": by / cnt,
                  "tflops": tf, "frac_of_mfma_peak": tf / peak, "gbs": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS,
                  "gemm_time_per_step_ms": total_t / nsteps * 1e3,
                  "all_gemm_tflops": sum(a[2] for a in agg.values()) / total_t / 1e12})
+    # the three largest GEMM configurations by time, for the record
+    roof["gemm_top"] = [{"kernel": k, "launches_per_step": v[0] // nsteps, "avg_launch_us": v[1] / v[0] * 1e6, "tflops": v[2] / v[1] / 1e12,
+                         "frac_of_mfma_peak": v[2] / v[1] / 1e12 / peak, "gbs": v[3] / v[1] / 1e9}
+                        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:5]]
+    # HBM-bound kernel families: algorithmic bytes (operands + results once) / event time, against 8 TB/s
+    fam = {}
+    for cname, nbytes, e0, e1 in calls:
+        a = fam.setdefault(cname, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += nbytes
+    roof["kernels"] = [{"kernel": k.replace("ast_", ""), "bound": "hbm", "launches_per_step": v[0] // nsteps, "time_per_step_us": v[1] / nsteps * 1e6,
+                        "achieved": v[2] / v[1] / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": v[2] / v[1] / 1e9 / PEAK_HBM_GBS}
+                       for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]) if v[1] > 0]
     return roof
 
 
 def ar_decode_bench(tr, x, labels, S, iters=20):
     """BASELINE configs[3]: the reference's process_audio (evaluation_style_transfer.py:135-159) for a batch of clips:
     eval-mode content encoder + autoregressive new_decoder generation of S sections + overlap-average + iSTFT ->
-    waveforms, as one replayed hipGraph (and eagerly, for comparison).  Class embeddings come from one style-encoder
-    pass beforehand, as the reference precomputes them."""
+    waveforms, as one replayed hipGraph (and eagerly), with the reference's recompute loop and with the KV-cached decode;
+    next to it the CPU oracle's timing of the same pipeline ("frames/sec vs CPU").  Class embeddings come from one
+    style-encoder pass beforehand, as the reference precomputes them."""
     from ast_amd import infer
     for m in (tr.style, tr.content, tr.decoder):
         m.eval()
@@ -125,24 +172,98 @@ def ar_decode_bench(tr, x, labels, S, iters=20):
         _, ce = tr.style(x, labels)
     cls = ce[labels.to(x.device)].contiguous()
     res = {}
-    for name, use_graph in (("graph", True), ("eager", False)):
-        sess = infer.StyleTransferSession(tr.content, tr.decoder, use_graph=use_graph)
-        for _ in range(3):
-            sess(x, cls)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            sess(x, cls)
-        torch.cuda.synchronize()
-        res[name] = (time.perf_counter() - t0) / iters
+    for mode in ("recompute", "kv_cache"):
+        type(tr.decoder).decode_mode = mode
+        for name, use_graph in (("graph", True), ("eager", False)):
+            sess = infer.StyleTransferSession(tr.content, tr.decoder, use_graph=use_graph)
+            for _ in range(3):
+                sess(x, cls)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                sess(x, cls)
+            torch.cuda.synchronize()
+            res[mode, name] = (time.perf_counter() - t0) / iters
+    type(tr.decoder).decode_mode = "recompute"
     for m in (tr.style, tr.content, tr.decoder):
         m.train()
     B = x.shape[0]
+    clip_s = {1: 3.0, 2: 4.0, 3: 8.0, 4: 10.0}[S]
     frames = B * (191 * (S - 1) + 287)
-    dt = res["graph"]
-    return {"ms_per_batch": dt * 1e3, "ms_per_batch_eager": res["eager"] * 1e3, "stft_frames_per_s": frames / dt,
-            "audio_seconds_per_s": B * CLIP_SECONDS / dt,
-            "note": "content encoder + O(S^2) AR decoder loop (new_decoder.py:272-319) + overlap-average + iSTFT to waveforms, one hipGraph"}
+    dt = min(res["recompute", "graph"], res["kv_cache", "graph"])
+    out = {"ms_per_batch": dt * 1e3, "ms_per_batch_recompute_graph": res["recompute", "graph"] * 1e3, "ms_per_batch_kv_cache_graph": res["kv_cache", "graph"] * 1e3,
+           "ms_per_batch_recompute_eager": res["recompute", "eager"] * 1e3, "ms_per_batch_kv_cache_eager": res["kv_cache", "eager"] * 1e3,
+           "stft_frames_per_s": frames / dt, "audio_seconds_per_s": B * clip_s / dt, "batch": B, "sections": S,
+           "note": "content encoder + autoregressive decoder (new_decoder.py:272-319) + overlap-average + iSTFT to waveforms, one hipGraph; "
+                   "recompute = the reference's O(S^2) loop, kv_cache = per-layer cached K/V (same results)"}
+    out["cpu"] = ar_decode_cpu(B, S, frames, clip_s)
+    out["speedup_vs_cpu"] = out["stft_frames_per_s"] / out["cpu"]["stft_frames_per_s"]
+    return out
+
+
+def ar_decode_cpu(B, S, frames, clip_s, reps=3):
+    """The oracle's eval-mode pipeline on the host cores: content encoder + AR decode + overlap-average + iSTFT."""
+    from oracle import ast_oracle as O
+    from oracle import frontend_oracle as FO
+    from oracle import layout as OL
+    from oracle import seeded_params as sp
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    sds = {t: OL.seeded_model_state(t, requires_grad=False) for t in ("content", "decoder")}
+    cfg = O.Cfg(training=False)
+    x = sp.seeded_input(B, S)
+    cls = sp.seeded_normal((B, 256), 5)
+    times = []
+    with torch.no_grad():
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            content = O.content_encoder_forward(sds["content"], x, cfg)
+            out = O.decoder_forward(sds["decoder"], content, cls, cfg, target_length=S).numpy()
+            for b in range(B):
+                FO.istft(FO.sections_to_spectrogram(out[b], 191 * (S - 1) + 287, 96))
+            times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    return {"s_per_batch": t, "stft_frames_per_s": frames / t, "audio_seconds_per_s": B * clip_s / t, "cores": torch.get_num_threads(),
+            "cpu_model": _cpu_model(), "kind": "port", "sample": f"oracle eval pipeline, B={B} S={S}, median of {reps}"}
+
+
+def mixed_bench(args, tr, dev, rank, world, barrier):
+    """BASELINE configs[4]: variable-length curriculum batches.  Seven length buckets (2..8 s); every step takes one bucket's
+    batch of B clips (resident waveforms -> STFT + CQT front end -> step); each bucket owns its front-end buffers and its
+    captured graph, so after the first visit every step is a replay.  value = true audio seconds / wall time."""
+    from ast_amd import train
+    from ast_amd.dataloader import sections_for_samples
+    lengths = [2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0]
+    buckets = []
+    for i, sec in enumerate(lengths):
+        waves, x, mean, std, labels = train.synthetic_waveform_batch(args.batch, sec, dev, seed=1000 + 17 * i + rank)
+        assert x.shape[1] == sections_for_samples(waves.shape[1])
+        buckets.append((sec, waves, x, mean, std, labels))
+    cq = (torch.zeros(2, 84, device=dev), torch.full((2, 84), 0.25, device=dev))
+
+    def run(k):
+        sec, waves, x, mean, std, labels = buckets[k % len(buckets)]
+        tr.set_frontend(waves, mean, std, *cq)
+        tr.step(x, labels)
+        return sec
+    for k in range(max(args.warmup, len(buckets))):         # every bucket captured once before timing
+        run(k)
+    barrier()
+    t0 = time.perf_counter()
+    secs = sum(run(k) for k in range(args.steps))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    if rank == 0:
+        print(json.dumps({"metric": "audio-seconds/sec/node (train step, mixed 2-8 s clips, bucketed by length)", "value": world * args.batch * secs / dt,
+                          "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                          "config": {"workload": f"configs[4]: clips of {lengths} s (S = {[b[2].shape[1] for b in buckets]}), batch={args.batch} per step and GPU, "
+                                                 "one length bucket per step in rotation, STFT + CQT front end inside the step, full train2 step",
+                                     "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": tr.cfg.use_graph,
+                                     "graphs_captured": len(tr._graphs)}}))
 
 
 def main():
@@ -157,6 +278,9 @@ def main():
     ap.add_argument("--no-cqt", action="store_true", help="front end runs the STFT only; the 84 CQT bins of x stay synthetic")
     ap.add_argument("--no-frontend", action="store_true", help="feed a resident model-ready x instead of running the STFT kernel each step")
     ap.add_argument("--infer", action="store_true", help="also time the autoregressive decode (BASELINE configs[3]) and add it to the JSON")
+    ap.add_argument("--mixed", action="store_true",
+                    help="BASELINE configs[4]: a stream of 2..8 s clips, one length bucket per step (S = 1,1,2,2,2,3,3), audio-seconds counted "
+                         "on the true clip lengths; replaces the fixed 4 s workload")
     ap.add_argument("--loss-matched", action="store_true",
                     help="N > 1: sync-BN + gathered batch-coupled losses (global-batch semantics, eager) instead of per-rank statistics")
     ap.add_argument("--decoder", default="new", choices=["new", "simple"],
@@ -206,6 +330,12 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.mixed:
+        mixed_bench(args, tr, dev, rank, world, barrier)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     for _ in range(args.warmup):
         tr.step(x, labels)

@@ -303,3 +303,48 @@ def test_simple_decoder_f32_vs_golden(golden_dir):
     with torch.no_grad():
         inf = m(content, cls)
     assert rel_err(inf[:, :, :, ::11, ::13], torch.from_numpy(g["infer_sub"])) < 1e-3
+
+
+@pytest.mark.parametrize("S", [2, 4])
+def test_kv_cached_decode_equals_recompute(S):
+    """the KV-cached autoregressive decode (one new token per step against per-layer cached K/V) gives the
+    reference loop's result (new_decoder.py:294-314 recomputes the whole stack over all generated tokens every step)."""
+    config.set_compute_dtype(torch.float32)
+    ms = build_models()
+    for m in ms.values():
+        m.eval()
+    B = 3
+    content = sp.seeded_normal((B, S, 256), 991).to(DEV)
+    cls = sp.seeded_normal((B, 256), 992).to(DEV)
+    dec = ms["decoder"]
+    with torch.no_grad():
+        dec.decode_mode = "recompute"
+        ref = dec(content, cls, target_length=S)
+        dec.decode_mode = "kv_cache"
+        try:
+            got = dec(content, cls, target_length=S)
+        finally:
+            dec.decode_mode = "recompute"
+    assert ref.shape == (B, S, 2, 287, 513) and float(ref.abs().max()) > 0
+    assert rel_err(got, ref) < 1e-5
+    # and against the oracle's autoregressive decode
+    sd = OL.seeded_model_state("decoder", requires_grad=False)
+    oo = O.decoder_forward(sd, content.cpu(), cls.cpu(), O.Cfg(training=False), target_length=S)
+    assert rel_err(got, oo) < 1e-3
+
+
+def test_reference_imports_resolve_to_the_dropin(golden_dir):
+    """with audio-style-transfer_amd/dropin first on sys.path the reference's own import lines
+    (evaluation_style_transfer.py:10-17) bind this implementation, and the step through those names reproduces the
+    reference's golden losses (tools/dropin_step.py, a fresh interpreter so the module names are really the shims')."""
+    import json, subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dropin_step.py")
+    out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    g = np.load(os.path.join(golden_dir, "model_b2s2.npz"))
+    assert r["module"] == "ast_amd.style_encoder" and r["stft_shape"] == [2, 87, 513]
+    assert math.isclose(r["total"], float(g["loss_total"]), rel_tol=1e-3)
+    assert math.isclose(r["rec"], float(g["rec_total_loss"]), rel_tol=1e-3)
+    assert math.isclose(r["adv_d"], float(g["loss_adv_d"]), rel_tol=1e-3)
+    assert r["grad"] > 0

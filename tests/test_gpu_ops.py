@@ -948,3 +948,20 @@ def test_checkpoint_layout_and_stft_stats(tmp_path):
     mean, std = st.finalize()
     assert rel_err(mean, torch.stack(means).mean(0)) < 1e-4
     assert rel_err(std, torch.stack(variances).mean(0).sqrt()) < 1e-4
+    # the full script: STFT || CQT (compute_unified_stats.py:25-68), against the same recipe on the oracle's STFT and CQT
+    from oracle import cqt_oracle as CO
+    us = CK.UnifiedStats(DEV)
+    means, variances = [], []
+    for i in range(3):
+        w = FO.synth_waveform(i, "piano" if i % 2 == 0 else "violin", seconds=2.0 + i)
+        us.add(torch.from_numpy(w))
+        merged = torch.from_numpy(np.concatenate([FO.stft(w), CO.get_cqt(w)], axis=2))
+        means.append(merged.mean(dim=1)); variances.append(merged.std(dim=1) ** 2)
+    sm, ss, cm, cs = us.finalize()
+    ref_m, ref_s = torch.stack(means).mean(0), torch.stack(variances).mean(0).sqrt()
+    assert sm.shape == (2, 513) and cm.shape == (2, 84)
+    assert rel_err(torch.cat([sm, cm], 1), ref_m) < 1e-4 and rel_err(torch.cat([ss, cs], 1), ref_s) < 1e-4
+    out = str(tmp_path / "stats_unified_stft_cqt.npz")
+    us.save(out)
+    z = np.load(out)
+    assert sorted(z.files) == ["cqt_mean", "cqt_std", "stft_mean", "stft_std"] and z["cqt_std"].shape == (2, 84)

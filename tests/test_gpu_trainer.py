@@ -253,3 +253,48 @@ def test_set_frontend_per_batch_under_graph():
         for k in e:
             tol = 5e-3 if i > 0 else (2e-3 if k in ("adv_g", "total") else 2e-4)
             assert math.isclose(e[k], g[k], rel_tol=tol, abs_tol=1e-5), (i, k, e[k], g[k])
+
+
+def test_mixed_length_stream_vs_oracle():
+    """BASELINE configs[4]: a stream of clips of different lengths (2 s, 4 s, 7 s -> S = 1, 2, 3) through ONE Trainer: each
+    length bucket gets its own front-end buffers and captured graph (the second visit of a bucket replays), and every
+    step's loss scalars follow the CPU oracle's trainer fed the oracle front end of the same waveforms."""
+    import numpy as np
+    from oracle import cqt_oracle as CO
+    from oracle import frontend_oracle as FO
+    from oracle import seeded_params as sp
+    from oracle.train_step import OracleTrainer
+    from ast_amd.dataloader import sections_for_samples
+    ast_amd.set_compute_dtype(torch.float32)
+    B = 2
+    g = np.random.default_rng(5)
+    mean, std = (0.01 * g.standard_normal((2, 513))).astype(np.float32), (0.5 + g.random((2, 513))).astype(np.float32)
+    cmean, cstd = np.zeros((2, 84), np.float32), np.full((2, 84), 0.25, np.float32)
+    labels = sp.balanced_labels(B)
+
+    def batch(seconds, seed):
+        waves = np.stack([FO.synth_waveform(seed + i, "piano" if i < B // 2 else "violin", seconds=seconds) for i in range(B)])
+        xs = []
+        for w in waves:
+            spec = np.concatenate([FO.normalize(FO.stft(w), mean, std), FO.normalize(CO.get_cqt(w), cmean, cstd)], axis=2)
+            xs.append(FO.overlap_windows(spec))
+        return waves.astype(np.float32), torch.from_numpy(np.stack(xs).astype(np.float32))
+
+    tr = train.Trainer(train.TrainConfig(use_graph=True, dropout=False), seed=7)
+    for tag, m in (("style", tr.style), ("content", tr.content), ("decoder", tr.decoder), ("disc", tr.disc)):
+        m.load_state_dict({k: v.to("cuda") for k, v in sp.seeded_state_dict(m.state_dict(), tag=tag).items()})
+    ot = OracleTrainer()
+    dev = lambda a: torch.from_numpy(a).cuda()          # noqa: E731
+    seq = [(2.0, 10), (4.0, 20), (7.0, 30), (4.0, 40), (2.0, 50)]
+    for i, (seconds, seed) in enumerate(seq):
+        waves, x_ref = batch(seconds, seed)
+        S = sections_for_samples(waves.shape[1])
+        assert x_ref.shape == (B, S, 2, 287, 597) and S == {2.0: 1, 4.0: 2, 7.0: 3}[seconds]
+        tr.set_frontend(dev(waves), dev(mean), dev(std), dev(cmean), dev(cstd))
+        got = {k: float(v) for k, v in tr.step(torch.zeros((B, S, 2, 287, 597), device="cuda"), labels).items()}
+        ref = ot.step(x_ref, labels)
+        for k in got:
+            # steps after the first carry the optimisers' state: f32 summation-order noise compounds (as test_trainer_modes_agree)
+            tol = 2e-2 if i > 0 else 2e-3
+            assert math.isclose(got[k], ref[k], rel_tol=tol, abs_tol=2e-4), (i, seconds, k, got[k], ref[k])
+    assert len(tr._graphs) == 3                            # one capture per length bucket; revisits replay

@@ -139,3 +139,21 @@ def test_cqt_plan_folds_librosa_steps_exactly():
     xp = np.pad(x, (width, width + 320 + kern.shape[1]))
     got = np.array([np.dot(kern[j % 147].astype(np.float64), xp[(j // 147) * 320:(j // 147) * 320 + kern.shape[1]]) for j in range(len(refr))])
     assert np.abs(got - refr).max() < 1e-6 and len(refr) == int(np.ceil(147 * 3000 / 320))
+
+
+def test_length_bucket_sampler_and_section_counts():
+    """BASELINE configs[4]: clip lengths 2..8 s give S = 1,1,2,2,2,3,3 (utilityFunctions.py:246-262) and the
+    sampler only ever mixes clips of one length in a batch."""
+    from ast_amd.dataloader import LengthBucketSampler, sections_for_samples
+    secs = [2, 3, 4, 5, 6, 7, 8, 10]
+    assert [sections_for_samples(s * 22050) for s in secs] == [1, 1, 2, 2, 2, 3, 3, 4]
+    lengths = [s * 22050 for s in (2, 4, 4, 7, 2, 4, 7, 2, 4, 2, 7, 7, 4, 3)]
+    sm = LengthBucketSampler(lengths, batch_size=2, shuffle=True, seed=3)
+    batches = list(sm)
+    assert len(batches) == len(sm) == 2 + 2 + 2          # 4 x 2 s, 5 x 4 s (one dropped), 4 x 7 s, 1 x 3 s (dropped)
+    for b in batches:
+        assert len({lengths[i] for i in b}) == 1
+    flat = [i for b in batches for i in b]
+    assert len(set(flat)) == len(flat)
+    sm.set_epoch(1)
+    assert list(sm) != batches                            # reshuffled per epoch
