@@ -55,6 +55,7 @@ _SIGS = {
     "ast_nhwc_to_nchw": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "ast_cast": ([vp, i32, vp, i32, i64, vp], i32),
     "ast_weights_prepare_t": ([vp, vp, i32, i32, i32, vp, i32, vp], i32),
+    "ast_sn_scratch_floats": ([i32, i32], C.c_long),
     "ast_weight_grads_flush_t": ([vp, vp, i32, vp], i32),
     "ast_dropout_fwd": ([vp, vp, vp, i64, f32, C.c_uint64, vp, vp], i32),
     "ast_weight_grad_unpack": ([vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp], i32),

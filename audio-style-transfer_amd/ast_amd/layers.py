@@ -82,7 +82,7 @@ class WeightBank:
                 e.wf = torch.empty(n, dtype=dt, device=dev)
                 e.wb = torch.empty(n, dtype=dt, device=dev)
                 e.sigma = torch.ones(1, dtype=torch.float32, device=dev)
-                e.scratch = torch.zeros(Co + Ci * KK, dtype=torch.float32, device=dev)
+                e.scratch = torch.zeros(int(lib().ast_sn_scratch_floats(Co, Ci * KK)), dtype=torch.float32, device=dev)
                 e.gtmp = torch.zeros(1, dtype=torch.float32, device=dev)
                 e.bias_pad = torch.zeros(pad8(Co), dtype=torch.float32, device=dev) if (bias is not None and Co != pad8(Co)) else None
             e.weight, e.u, e.v, e.bias, e.bank = w, u, v, bias, self

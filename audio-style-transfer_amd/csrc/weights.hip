@@ -14,8 +14,10 @@ __device__ __forceinline__ size_t woff(const ast_weight_desc_t& d, int co, int c
 }
 
 // t[j] = sum_co W(co, j) u[co],  j = ci*KK + tap  -> scratch[Co + j]
-// rows are split over grid.z (RZ chunks) and summed with atomics; scratch[Co..] is zeroed by sn_sigma_kernel
-// of the previous forward (and at allocation), so the launch needs no memset.
+// The rows are split over grid.z (RZ chunks) for parallelism.  Every chunk STORES its partial sum into its own slab
+// scratch[Co + ncols*(1 + z) ..] and sn_t_sum_kernel adds the slabs in a fixed order: u, v and sigma are then
+// bit-reproducible (they are never communicated between data-parallel replicas, so every replica must compute the same
+// bits from the same weights -- SURVEY 5.8; f32 atomics, used here before, made them depend on arrival order).
 constexpr int RZ = 32;
 __global__ __launch_bounds__(256) void sn_wt_u_kernel(const ast_weight_desc_t* __restrict__ descs) {
   const ast_weight_desc_t d = descs[blockIdx.y];
@@ -24,6 +26,7 @@ __global__ __launch_bounds__(256) void sn_wt_u_kernel(const ast_weight_desc_t* _
   const int rows_per = (d.Co + RZ - 1) / RZ;
   const int c0 = blockIdx.z * rows_per, c1 = min(d.Co, c0 + rows_per);
   if (c0 >= c1) return;
+  float* part = d.scratch + d.Co + (size_t)ncols * (1 + blockIdx.z);
   if (d.s_ci == d.KK && (ncols & 3) == 0 && (d.s_co & 3) == 0 && (((uintptr_t)d.w) & 15) == 0) {
     // Conv2d / Linear layout: rows are contiguous in j -> each thread owns 4 columns (16-byte loads); the first
     // quarter of the grid covers all columns, the rest exits
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(256) void sn_wt_u_kernel(const ast_weight_desc_t* _
       acc4[0] += w4[0] * uc; acc4[1] += w4[1] * uc; acc4[2] += w4[2] * uc; acc4[3] += w4[3] * uc;
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(d.scratch + d.Co + j4 * 4 + e, acc4[e]);
+    for (int e = 0; e < 4; ++e) part[j4 * 4 + e] = acc4[e];
     return;
   }
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -44,7 +47,22 @@ __global__ __launch_bounds__(256) void sn_wt_u_kernel(const ast_weight_desc_t* _
   const int ci = j / d.KK, tap = j - ci * d.KK;
   float acc = 0.f;
   for (int co = c0; co < c1; ++co) acc += d.w[woff(d, co, ci, tap)] * d.u[co];
-  unsafeAtomicAdd(d.scratch + d.Co + j, acc);
+  part[j] = acc;
+}
+
+// t[j] = sum over the row chunks, in chunk order
+__global__ __launch_bounds__(256) void sn_t_sum_kernel(const ast_weight_desc_t* __restrict__ descs) {
+  const ast_weight_desc_t d = descs[blockIdx.y];
+  if (!d.u || !d.power_iter) return;
+  const int ncols = d.Ci * d.KK;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= ncols) return;
+  const int rows_per = (d.Co + RZ - 1) / RZ;
+  const int nz = (d.Co + rows_per - 1) / rows_per;           // chunks that hold rows
+  const float* part = d.scratch + d.Co + ncols;
+  float t = 0.f;
+  for (int z = 0; z < nz; ++z) t += part[(size_t)z * ncols + j];
+  d.scratch[d.Co + j] = t;
 }
 
 // v = t/|t| (training) ; s[co] = sum_j W(co,j) v[j] -> scratch[co]; one wave per row
@@ -247,7 +265,6 @@ __global__ __launch_bounds__(256) void sn_sigma_kernel(const ast_weight_desc_t* 
   }
   if (threadIdx.x == 0) d.sigma[0] = sigma;
   __syncthreads();
-  for (int j = threadIdx.x; j < d.Ci * d.KK; j += 256) d.scratch[d.Co + j] = 0.f;   // t = W^T u zeroed for the next forward's atomics
 }
 
 template <int KKC>
@@ -418,6 +435,7 @@ extern "C" int ast_weights_prepare_t(const ast_weight_desc_t* descs, const int* 
   if (!descs || !dtypes || !tiles || n <= 0 || ntiles <= 0 || max_co <= 0 || max_cols <= 0) AST_FAIL("ast_weights_prepare_t: bad args");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(sn_wt_u_kernel, dim3((max_cols + 255) / 256, n, RZ), dim3(256), 0, s, descs);
+  hipLaunchKernelGGL(sn_t_sum_kernel, dim3((max_cols + 255) / 256, n), dim3(256), 0, s, descs);
   hipLaunchKernelGGL(sn_w_v_kernel, dim3((max_co + 3) / 4, n), dim3(256), 0, s, descs);
   hipLaunchKernelGGL(sn_sigma_kernel, dim3(n), dim3(256), 0, s, descs);
   hipLaunchKernelGGL(pack_tiles_kernel, dim3(ntiles), dim3(256), 0, s, descs, dtypes, (const WTile*)tiles);
@@ -449,4 +467,9 @@ extern "C" int ast_weight_grad_unpack(const float* dwp, int from_wb, const float
                      s_ci, Cop, Cip);
   AST_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" long ast_sn_scratch_floats(int Co, int ncols) {
+  if (Co < 1 || ncols < 1) return -1;
+  return (long)Co + (long)ncols * (1 + RZ);          // s = W v, t = W^T u, and the RZ row-chunk partial sums of t
 }

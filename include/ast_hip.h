@@ -126,7 +126,7 @@ typedef struct ast_weight_desc_t {
   float* u;             /* weight_u [Co] or NULL (no spectral norm) */
   float* v;             /* weight_v [Ci*KK] */
   float* sigma;         /* [1] out */
-  float* scratch;       /* [Co + Ci*KK] */
+  float* scratch;       /* [ast_sn_scratch_floats(Co, Ci*KK)] = Co + Ci*KK*(1 + 32): s = W v, t = W^T u, row-chunk partials of t */
   void* wf;             /* packed [Cop][KK][Cip]  (rows = out channel) or NULL */
   void* wb;             /* packed [Cip][KK][Cop]  (rows = in channel) or NULL */
   int32_t Co, Ci, KK, s_co, s_ci, Cop, Cip;
@@ -140,8 +140,12 @@ typedef struct ast_weight_desc_t {
 /* descs: DEVICE array of n descriptors, dtypes: DEVICE int[n] (packed dtype per weight), tiles: DEVICE array of
  * {int32 weight index, co0, ci0, pad} covering every 32x32 channel tile of every weight (padded extents).
  * prepare: power iteration (if requested), sigma = u^T W v, W/sigma written in both packed layouts and the
- * gradient staging zeroed -- four launches for all n weights; LDS-tiled so every global access is a contiguous run.
+ * gradient staging zeroed -- five launches for all n weights; LDS-tiled so every global access is a contiguous run.
+ * u, v and sigma are BIT-REPRODUCIBLE functions of (w, u): W^T u is summed over 32 row chunks through per-chunk slabs in a
+ * fixed order (no float atomics), so data-parallel replicas -- which never exchange these buffers -- stay identical.
  * flush (once after backward): grad += (dWp - <dWp,W/sigma> u v^T)/sigma for every weight -- two launches. */
+/* floats of ast_weight_desc_t.scratch for a (Co x ncols) weight */
+long ast_sn_scratch_floats(int Co, int ncols);
 int ast_weights_prepare_t(const ast_weight_desc_t* descs, const int* dtypes, int n, int max_co, int max_cols,
                           const void* tiles, int ntiles, void* stream);
 int ast_weight_grads_flush_t(const ast_weight_desc_t* descs, const void* tiles, int ntiles, void* stream);

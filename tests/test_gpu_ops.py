@@ -965,3 +965,34 @@ def test_checkpoint_layout_and_stft_stats(tmp_path):
     us.save(out)
     z = np.load(out)
     assert sorted(z.files) == ["cqt_mean", "cqt_std", "stft_mean", "stft_std"] and z["cqt_std"].shape == (2, 84)
+
+
+def test_spectral_norm_state_is_bit_reproducible():
+    """weight_u / weight_v are never exchanged between data-parallel replicas, so every replica must compute
+    the same BITS from the same weights.  Two replicas of an encoder, three power iterations each: every u, v buffer and
+    the packed weights are bit-equal (the row-chunk sums of W^T u go through fixed-order slabs, not float atomics)."""
+    config.set_compute_dtype(torch.bfloat16)
+    try:
+        reps = []
+        for _ in range(2):
+            m = ast_amd.StyleEncoder()
+            m.load_state_dict(sp.seeded_state_dict(m.state_dict(), tag="style"))
+            m = m.to(DEV).train()
+            from ast_amd.style_encoder import _module_bank
+            bank = _module_bank(m)
+            for _ in range(3):
+                bank.prepare(True)
+            torch.cuda.synchronize()
+            reps.append((m, bank))
+        (m0, b0), (m1, b1) = reps
+        sd0, sd1 = m0.state_dict(), m1.state_dict()
+        n = 0
+        for k in sd0:
+            if k.endswith(("weight_u", "weight_v")):
+                assert torch.equal(sd0[k], sd1[k]), k
+                n += 1
+        assert n == 36                                   # 18 spectrally normalised convolutions
+        for e0, e1 in zip(b0.entries, b1.entries):
+            assert torch.equal(e0.sigma, e1.sigma) and torch.equal(e0.wf.view(torch.int16), e1.wf.view(torch.int16))
+    finally:
+        config.set_compute_dtype(torch.float32)
