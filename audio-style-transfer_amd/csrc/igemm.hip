@@ -600,8 +600,10 @@ template <typename T> struct WgradCfg;
 template <> struct WgradCfg<bf16_t> { static constexpr int BKP = 64, PAD = 8; };    // elements
 template <> struct WgradCfg<float> { static constexpr int BKP = 32, PAD = 16; };
 
-template <typename T, int BMW, int NCT>
-__global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ src,
+// PG pixel groups of 4 waves per workgroup, as in wgrad_halo_kernel: group pg takes every PG-th K tile of the workgroup's pixel
+// slice through its own LDS staging, partial tiles are summed through LDS, one atomic flush per workgroup.
+template <typename T, int BMW, int NCT, int PG>
+__global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ src,
                                                      float* __restrict__ dw, const ast_gather_t g,
                                                      const int P, const int pps, const unsigned dy_bytes,
                                                      const unsigned src_bytes, const float rcp_hw, const float rcp_w,
@@ -616,12 +618,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dy, co
   constexpr int RT = BMW / 16;                      // row (cd) tiles, all handled by every wave
   constexpr int CTW = (NCT + 3) / 4;                // column tiles per wave
   constexpr unsigned OOB = 0x80000000u;
-  extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char wl_all[];
+  constexpr int GROUP_BYTES = (int)sizeof(T) * BKP * (PY + PX);
+  constexpr int RED = PG > 1 ? RT * CTW * 256 * 16 : 0;                        // one group's partial tile in the final LDS reduction
+  constexpr int TAP_OFF = (PG * GROUP_BYTES > RED ? PG * GROUP_BYTES : RED);
+  const int pg = PG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
+  unsigned char* wl = wl_all + pg * GROUP_BYTES;
   T* Ys = reinterpret_cast<T*>(wl);
   T* Xs = Ys + BKP * PY;
-  int* taptab = reinterpret_cast<int*>(Xs + BKP * PX);
+  int* taptab = reinterpret_cast<int*>(wl_all + TAP_OFF);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   // XCD-aware order (workgroups b and b+8 share an L2): XCD x takes the x-th contiguous eighth of the tiles in
   // (row tile, pixel slice, column tile) order, so an L2 holds ONE channel slice of dy (deep layers: Cd/64 >= 8 row
   // tiles) or ONE band of pixels (shallow layers: many pixel slices) instead of a sample of the whole layer.  Measured
@@ -638,7 +645,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dy, co
   const __amdgpu_buffer_rsrc_t srcR = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, src_bytes, 0x00020000);
 #pragma unroll
   for (int t = 0; t < AST_MAX_TAPS; ++t)
-    if (tid == t) taptab[t] = g.tap[t];
+    if ((int)threadIdx.x == t) taptab[t] = g.tap[t];
   __syncthreads();
 
   // loader role: one pixel row per thread, chunks tq, tq + TPR, ...
@@ -697,12 +704,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dy, co
     for (int j = 0; j < CTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int li = lane & 15, gq = lane >> 4;
-  const int nk = (p_end - p_begin + BKP - 1) / BKP;
-  if (nk > 0) load_tile(p_begin);
+  const int nk_all = (p_end - p_begin + BKP - 1) / BKP;
+  const int nk = (nk_all + PG - 1) / PG;                         // trips: every group runs all of them (workgroup-wide barriers);
+  if (nk > 0) load_tile(p_begin + pg * BKP);                    // a group past the slice's end loads zeros (p >= p_end)
   for (int kt = 0; kt < nk; ++kt) {
     store_tile();
     __syncthreads();
-    if (kt + 1 < nk) load_tile(p_begin + (kt + 1) * BKP);       // in flight while this tile is consumed
+    if (kt + 1 < nk) load_tile(p_begin + ((kt + 1) * PG + pg) * BKP);       // in flight while this tile is consumed
     if constexpr (sizeof(T) == 2) {
       typedef __attribute__((address_space(3))) bf16x4 lds_b4;
       const int q = li >> 2, pcol = (li & 3) * 4;                // lane 4q+p supplies row q, columns 4p..4p+3 of its 16-lane group
@@ -748,6 +756,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dy, co
     __syncthreads();                                             // operand reads done before the next store
   }
 
+  if constexpr (PG > 1) {                           // sum the groups' partial tiles through LDS (the staging is free now)
+    f32x4* red = reinterpret_cast<f32x4*>(wl_all);
+#pragma unroll
+    for (int src_g = 1; src_g < PG; ++src_g) {
+      __syncthreads();
+      if (pg == src_g) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < CTW; ++j) red[(i * CTW + j) * 256 + tid] = acc[i][j];
+      }
+      __syncthreads();
+      if (pg == 0) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < CTW; ++j) {
+            const f32x4 t = red[(i * CTW + j) * 256 + tid];
+            acc[i][j][0] += t[0]; acc[i][j][1] += t[1]; acc[i][j][2] += t[2]; acc[i][j][3] += t[3];
+          }
+      }
+    }
+    if (pg > 0) return;
+  }
   // D[row = cd (gq*4+r)][col = column li]
 #pragma unroll
   for (int j = 0; j < CTW; ++j) {
@@ -767,13 +799,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ dy, co
   }
 }
 
-template <typename T, int BMW, int NCT>
-int launch_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t& g, int P, hipStream_t s) {
+template <typename T, int BMW, int NCT, int PG>
+int launch_wgrad_pg(const void* dy, const void* src, float* dw, const ast_gather_t& g, int P, hipStream_t s) {
   constexpr int BKP = WgradCfg<T>::BKP, PAD = WgradCfg<T>::PAD;
-  constexpr int LDS = (int)sizeof(T) * BKP * ((BMW + PAD) + (NCT * 16 + PAD)) + 64;
+  constexpr int GROUP = (int)sizeof(T) * BKP * ((BMW + PAD) + (NCT * 16 + PAD));
+  constexpr int RED = PG > 1 ? (BMW / 16) * ((NCT + 3) / 4) * 256 * 16 : 0;
+  constexpr int LDS = (PG * GROUP > RED ? PG * GROUP : RED) + 64;
   static bool attr_set = false;
   if (!attr_set) {
-    AST_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<T, BMW, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    AST_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<T, BMW, NCT, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   const int gx = (g.Cd + BMW - 1) / BMW, gy = (g.ntaps * g.Cs + NCT * 16 - 1) / (NCT * 16);
@@ -786,10 +820,21 @@ int launch_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t&
   const unsigned dy_bytes = (unsigned)((size_t)P * g.Cd * sizeof(T));
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
   const int total = gx * gy * nsplit;
-  hipLaunchKernelGGL((wgrad_kernel<T, BMW, NCT>), dim3((total + 7) / 8 * 8), dim3(256), LDS, s, (const T*)dy, (const T*)src, dw, g, P, pps,
+  hipLaunchKernelGGL((wgrad_kernel<T, BMW, NCT, PG>), dim3((total + 7) / 8 * 8), dim3(256 * PG), LDS, s, (const T*)dy, (const T*)src, dw, g, P, pps,
                      dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm, gx, gy, nsplit);
   AST_CHECK_LAUNCH();
   return 0;
+}
+
+template <typename T, int BMW, int NCT>
+int launch_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t& g, int P, hipStream_t s) {
+  // two pixel groups for the pixel-rich layers only: measured 172 800 pixels -11 % (51 -> 45 us), 43 200 pixels +20 %
+  // (54 -> 65 us: their slices are a few K tiles long, halving them leaves the groups idle at the barriers)
+  const char* pe = getenv("AST_WGRAD_PG");
+  const char* mp = getenv("AST_WGRAD_PG_MINP");
+  const int pg = pe ? atoi(pe) : 2;
+  if (pg >= 2 && P >= (mp ? atoi(mp) : 100000)) return launch_wgrad_pg<T, BMW, NCT, 2>(dy, src, dw, g, P, s);
+  return launch_wgrad_pg<T, BMW, NCT, 1>(dy, src, dw, g, P, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -804,8 +849,12 @@ int launch_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t&
 constexpr int WH_TH = 8, WH_TW = 16, WH_MAXPL = 10;
 struct WHaloPlan { int PH, PW, dhmin, dwmin, tiles_h, tiles_w, ntiles, lds; };
 
-template <typename T, int BMW, int NCT>
-__global__ __launch_bounds__(256) void wgrad_halo_kernel(const T* __restrict__ dy, const T* __restrict__ src,
+// PG: pixel groups.  The workgroup has PG groups of 4 waves; group pg streams tiles blockIdx.z*PG + pg, + gridDim.z*PG, ...
+// through its OWN LDS staging and accumulators, and the groups' partial tiles are summed through LDS before ONE atomic flush per
+// workgroup.  Same-address f32 atomics serialise (~38 ns per workgroup per address on the 16x72 gradient of the 2.4 M-pixel
+// layer: 768 -> 3072 workgroups took 77 -> 164 us), so parallelism has to come from waves per workgroup, not from workgroups.
+template <typename T, int BMW, int NCT, int PG>
+__global__ __launch_bounds__(256 * PG) void wgrad_halo_kernel(const T* __restrict__ dy, const T* __restrict__ src,
                                                           float* __restrict__ dw, const ast_gather_t g, const WHaloPlan hp,
                                                           const unsigned dy_bytes, const unsigned src_bytes) {
   constexpr int E = 16 / sizeof(T), ES = sizeof(T);
@@ -816,13 +865,17 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const T* __restrict__ d
   constexpr int NYI = (MT * CPY + 255) / 256;
   constexpr int RT = BMW / 16, CTW = (NCT + 3) / 4;
   constexpr unsigned OOB = 0x80000000u;
-  extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char wl_all[];
+  const int pg = PG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;      // wave-uniform
+  const int PPX = g.Cs + (sizeof(T) == 2 ? 8 : 4);  // patch pixel pitch (elements): breaks the power-of-two stride
+  const int group_bytes = ((int)sizeof(T) * (MT * PY + hp.PH * hp.PW * PPX) + 15) & ~15;
+  unsigned char* wl = wl_all + pg * group_bytes;
   T* Ys = reinterpret_cast<T*>(wl);
   T* Xp = Ys + MT * PY;                             // patch [PH*PW][Cs + pad]
-  const int PPX = g.Cs + (sizeof(T) == 2 ? 8 : 4);  // patch pixel pitch (elements): breaks the power-of-two stride
-  int* taptab = reinterpret_cast<int*>(Xp + hp.PH * hp.PW * PPX);
+  constexpr int RED = PG > 1 ? (BMW / 16) * ((NCT + 3) / 4) * 256 * 16 : 0;     // bytes of one group's partial tile in the final LDS reduction
+  int* taptab = reinterpret_cast<int*>(wl_all + max(PG * group_bytes, RED));   // behind both uses of the staging area
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int cd0 = blockIdx.x * BMW, col0 = blockIdx.y * NCT * 16;
   const int ncols = g.ntaps * g.Cs;
   const int UP = g.Cs / E;                          // 16-byte chunks per patch pixel
@@ -831,7 +884,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const T* __restrict__ d
   const __amdgpu_buffer_rsrc_t srcR = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, src_bytes, 0x00020000);
 #pragma unroll
   for (int t = 0; t < AST_MAX_TAPS; ++t)
-    if (tid == t) {
+    if ((int)threadIdx.x == t) {
       int dh, dwv, wt;
       decode_tap(g.tap[t], dh, dwv, wt);
       taptab[t] = ((dh - hp.dhmin) * PW + (dwv - hp.dwmin)) * PPX;   // patch element offset of the tap
@@ -880,7 +933,9 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const T* __restrict__ d
     for (int j = 0; j < CTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 preg[WH_MAXPL], yreg[NYI];
-  auto load_tile = [&](int tile) __attribute__((always_inline)) {
+  auto load_tile = [&](int tile_in) __attribute__((always_inline)) {
+    const bool tvalid = tile_in < hp.ntiles;          // a group past its last tile loads zeros (every offset out of range)
+    const int tile = tvalid ? tile_in : 0;
     const int per_img = hp.tiles_h * hp.tiles_w;
     const int n = tile / per_img, r = tile - n * per_img;
     const int th = r / hp.tiles_w, tw = r - th * hp.tiles_w;
@@ -889,7 +944,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const T* __restrict__ d
     const int base = (((n * g.Hs + hs_org) * g.Ws + ws_org) * g.Cs) * ES;
 #pragma unroll
     for (int i = 0; i < WH_MAXPL; ++i) {
-      const bool ok = plo[i] >= 0 && (unsigned)(hs_org + ppy[i]) < (unsigned)g.Hs && (unsigned)(ws_org + ppx[i]) < (unsigned)g.Ws;
+      const bool ok = tvalid && plo[i] >= 0 && (unsigned)(hs_org + ppy[i]) < (unsigned)g.Hs && (unsigned)(ws_org + ppx[i]) < (unsigned)g.Ws;
       preg[i] = __builtin_amdgcn_raw_buffer_load_b128(srcR, ok ? (unsigned)(base + pgo[i]) : OOB, 0, 0);
     }
 #pragma unroll
@@ -897,7 +952,7 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const T* __restrict__ d
       const int ty = ypix[i] >> 4, tx = ypix[i] & 15;
       const int hm = hm0 + ty, wq = wm0 + tx;
       const int cd = cd0 + ych[i] * E;
-      const bool ok = ypix[i] >= 0 && hm < g.Hm && wq < g.Wm && cd < g.Cd;
+      const bool ok = tvalid && ypix[i] >= 0 && hm < g.Hm && wq < g.Wm && cd < g.Cd;
       yreg[i] = __builtin_amdgcn_raw_buffer_load_b128(dyR, ok ? (unsigned)((((n * g.Hm + hm) * g.Wm + wq) * g.Cd + cd) * ES) : OOB, 0, 0);
     }
   };
@@ -910,12 +965,16 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const T* __restrict__ d
       if (ypix[i] >= 0) *reinterpret_cast<u32x4*>(Ys + ypix[i] * PY + ych[i] * E) = yreg[i];
   };
 
-  int tile = blockIdx.z;
-  if (tile < hp.ntiles) load_tile(tile);
-  for (; tile < hp.ntiles; tile += gridDim.z) {
+  // every group runs the workgroup's trip count (the barriers are workgroup-wide); a group without a tile works on zeros
+  const int tstride = gridDim.z * PG;
+  const int first = blockIdx.z * PG;
+  const int ntrips = first < hp.ntiles ? (hp.ntiles - first + tstride - 1) / tstride : 0;
+  int tile = first + pg;
+  if (ntrips > 0) load_tile(tile);
+  for (int trip = 0; trip < ntrips; ++trip, tile += tstride) {
     store_tile();
     __syncthreads();
-    if (tile + (int)gridDim.z < hp.ntiles) load_tile(tile + gridDim.z);     // next tile in flight during the MFMAs
+    if (trip + 1 < ntrips) load_tile(tile + tstride);                        // next tile in flight during the MFMAs
     if constexpr (sizeof(T) == 2) {
       typedef __attribute__((address_space(3))) bf16x4 lds_b4;
       const int q = li >> 2, pcol = (li & 3) * 4;
@@ -964,6 +1023,30 @@ __global__ __launch_bounds__(256) void wgrad_halo_kernel(const T* __restrict__ d
     __syncthreads();
   }
 
+  if constexpr (PG > 1) {                           // sum the groups' partial tiles through LDS (the staging is free now)
+    f32x4* red = reinterpret_cast<f32x4*>(wl_all);
+#pragma unroll
+    for (int src_g = 1; src_g < PG; ++src_g) {
+      __syncthreads();
+      if (pg == src_g) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < CTW; ++j) red[(i * CTW + j) * 256 + tid] = acc[i][j];
+      }
+      __syncthreads();
+      if (pg == 0) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < CTW; ++j) {
+            const f32x4 t = red[(i * CTW + j) * 256 + tid];
+            acc[i][j][0] += t[0]; acc[i][j][1] += t[1]; acc[i][j][2] += t[2]; acc[i][j][3] += t[3];
+          }
+      }
+    }
+    if (pg > 0) return;
+  }
   // D[row = cd (gq*4+r)][col = column li]
 #pragma unroll
   for (int j = 0; j < CTW; ++j) {
@@ -998,32 +1081,46 @@ bool plan_wgrad_halo(const ast_gather_t& g, int dtype, int nct, int bmw, WHaloPl
   hp.tiles_h = (g.Hm + WH_TH - 1) / WH_TH; hp.tiles_w = (g.Wm + WH_TW - 1) / WH_TW;
   hp.ntiles = g.N * hp.tiles_h * hp.tiles_w;
   const int ppx = g.Cs + (ES == 2 ? 8 : 4), pady = ES == 2 ? 8 : 16;
-  hp.lds = ES * (WH_TH * WH_TW * (bmw + pady) + hp.PH * hp.PW * ppx) + 160;
+  hp.lds = ((ES * (WH_TH * WH_TW * (bmw + pady) + hp.PH * hp.PW * ppx) + 15) & ~15);      // one group's staging
   if (hp.lds > 96 * 1024) return false;
   // tile quantisation: skip when the 8x16 tiling wastes most of the work (tiny images go to the gathered kernel)
   const double eff = (double)g.Hm * g.Wm / ((double)hp.tiles_h * hp.tiles_w * WH_TH * WH_TW);
   return eff >= 0.6 && hp.ntiles >= 256;
 }
 
-template <typename T, int BMW, int NCT>
-int launch_wgrad_halo(const void* dy, const void* src, float* dw, const ast_gather_t& g, const WHaloPlan& hp, hipStream_t s) {
+template <typename T, int BMW, int NCT, int PG>
+int launch_wgrad_halo_pg(const void* dy, const void* src, float* dw, const ast_gather_t& g, const WHaloPlan& hp, hipStream_t s) {
+  constexpr int RED = (BMW / 16) * ((NCT + 3) / 4) * 256 * 16;          // bytes of one group's partial tile in the LDS reduction
+  const int lds = std::max(PG * hp.lds, PG > 1 ? RED : 0) + 160;
   static int attr_lds = 0;
-  if (hp.lds > attr_lds) {
-    AST_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<T, BMW, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr_lds = 96 * 1024;
+  if (lds > attr_lds) {
+    AST_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<T, BMW, NCT, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_lds = 160 * 1024;
   }
   const int gx = (g.Cd + BMW - 1) / BMW, gy = (g.ntaps * g.Cs + NCT * 16 - 1) / (NCT * 16);
-  // every workgroup adds its whole dW tile into the same few KB: fewer workgroups = less same-address atomic
-  // contention; only the largest pixel counts need more than one workgroup per CU (sweep in profiles/r01)
+  // every workgroup adds its whole dW tile into the same few KB: same-address atomics serialise, so the workgroup count
+  // stays at about one per CU and the waves come from the pixel groups (sweep in profiles/r01 and r02)
   const char* wt = getenv("AST_WGRAD_WG_TARGET");
-  const int wg_target = wt ? atoi(wt) : ((long)g.N * g.Hm * g.Wm >= 1500000 ? 768 : 256);
-  const int gz = std::max(1, std::min(hp.ntiles, wg_target / (gx * gy)));
+  const int wg_target = wt ? atoi(wt) : (PG > 1 ? 256 : ((long)g.N * g.Hm * g.Wm >= 1500000 ? 768 : 256));
+  const int gz = std::max(1, std::min((hp.ntiles + PG - 1) / PG, wg_target / (gx * gy)));
   const unsigned dy_bytes = (unsigned)((size_t)g.N * g.Hm * g.Wm * g.Cd * sizeof(T));
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
-  hipLaunchKernelGGL((wgrad_halo_kernel<T, BMW, NCT>), dim3(gx, gy, gz), dim3(256), hp.lds, s, (const T*)dy, (const T*)src, dw, g, hp,
+  hipLaunchKernelGGL((wgrad_halo_kernel<T, BMW, NCT, PG>), dim3(gx, gy, gz), dim3(256 * PG), lds, s, (const T*)dy, (const T*)src, dw, g, hp,
                      dy_bytes, src_bytes);
   AST_CHECK_LAUNCH();
   return 0;
+}
+
+template <typename T, int BMW, int NCT>
+int launch_wgrad_halo(const void* dy, const void* src, float* dw, const ast_gather_t& g, const WHaloPlan& hp, hipStream_t s) {
+  // pixel groups: as many as the LDS holds (<= 4), when every group gets several tiles
+  // (four groups need <= 128 VGPRs per thread; the kernel uses 130-200 and spills: 50 -> 105 us on the 32-channel layer)
+  const char* pe = getenv("AST_WGRAD_PG");
+  int pg = pe ? atoi(pe) : 2;
+  while (pg > 1 && (pg * hp.lds > 150 * 1024 || hp.ntiles < 256 * pg * 2)) pg >>= 1;
+  if (pg >= 4) return launch_wgrad_halo_pg<T, BMW, NCT, 4>(dy, src, dw, g, hp, s);
+  if (pg == 2) return launch_wgrad_halo_pg<T, BMW, NCT, 2>(dy, src, dw, g, hp, s);
+  return launch_wgrad_halo_pg<T, BMW, NCT, 1>(dy, src, dw, g, hp, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -9,23 +9,29 @@ from ast_amd import ops
 from ast_amd._lib import lib, check, ptr, stream, dcode
 SH = {"b5c2": (16, 5, 10, 512, 512, 3, 1), "b4c2": (16, 9, 19, 512, 512, 3, 1), "b3c2": (16, 18, 38, 256, 256, 3, 1),
       "b2c2": (16, 36, 75, 128, 128, 3, 1), "b1c2": (16, 72, 150, 64, 64, 3, 1), "b0c2": (16, 144, 299, 32, 32, 3, 1),
-      "b1c1": (16, 144, 299, 32, 64, 3, 2), "b2c1": (16, 72, 150, 64, 128, 3, 2)}
+      "b1c1": (16, 144, 299, 32, 64, 3, 2), "b2c1": (16, 72, 150, 64, 128, 3, 2),
+      "dec0": (16, 287, 513, 8, 16, 3, 1), "b0c1": (16, 287, 597, 8, 32, 3, 2), "b0ds": (16, 287, 597, 8, 32, 1, 2),
+      "dec1": (16, 287, 513, 16, 32, 3, 2)}
 layers = (sys.argv[1] if len(sys.argv) > 1 else "b0c2,b1c2,b2c2,b3c2").split(",")
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 wgrad = len(sys.argv) > 3 and sys.argv[3] == "wgrad"
 dt = torch.bfloat16
 for name in layers:
     N, H, W, Cs, Cd, k, st = SH[name]
-    g, (Ho, Wo) = ops.gather_direct(N, H, W, Cs, Cd, k, st, 1)
+    g, (Ho, Wo) = ops.gather_direct(N, H, W, Cs, Cd, k, st, 1 if k == 3 else 0)
     x = torch.randn(N, H, W, Cs, device="cuda").to(dt); w = (0.05 * torch.randn(Cd, k * k, Cs, device="cuda")).to(dt)
     y = torch.empty(N, Ho, Wo, Cd, device="cuda", dtype=dt)
     stats = torch.zeros(64 * Cd * 2, device="cuda")
+    wsz = torch.zeros(N * Ho * Wo * Cd, device="cuda")
     dy = torch.randn(N, Ho, Wo, Cd, device="cuda").to(dt); dw = torch.zeros(Cd, k * k, Cs, device="cuda")
     def run():
         if wgrad:
             check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(dw), g, dcode(dt), stream()))
         else:
-            check(lib().ast_igemm(ptr(x), ptr(w), None, ptr(y), g, dcode(dt), 8, ptr(stats), stats.numel(), stream()))
+            if os.environ.get("NOSTATS"):
+                check(lib().ast_igemm(ptr(x), ptr(w), None, ptr(y), g, dcode(dt), 4, ptr(wsz), wsz.numel(), stream()))
+            else:
+                check(lib().ast_igemm(ptr(x), ptr(w), None, ptr(y), g, dcode(dt), 8, ptr(stats), stats.numel(), stream()))
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,4 +40,5 @@ for name in layers:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     fl = 2.0 * N * Ho * Wo * Cd * k * k * Cs
-    print(f"{name} {'wgrad' if wgrad else 'fwd+stats'} {ops._igemm_config(g, dcode(dt)) if not wgrad else ''}: {us:7.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
+    nbytes = (N * Ho * Wo * Cd + N * H * W * Cs) * 2
+    print(f"{name} {'wgrad' if wgrad else 'fwd+stats'} {ops._igemm_config(g, dcode(dt)) if not wgrad else ''}: {us:7.1f} us  {fl / us / 1e6:7.1f} TF/s  {nbytes / us / 1e3:6.0f} GB/s", flush=True)
