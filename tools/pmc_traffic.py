@@ -11,6 +11,10 @@ def label(name):
     if m:
         dt, bm, bn, kch, kg = m.groups()
         return f"igemm_kernel<{'bf16' if dt == 'DF16b' else 'f32'},{bm}x{bn},k{int(kch) * 16}B" + (f",kg{kg}" if kg != "1" else "") + ">"
+    m = re.search(r"pconv_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)E", name)
+    if m:
+        dt, slb, tm, tn = m.groups()
+        return f"pconv_kernel<{'bf16' if dt == 'DF16b' else 'f32'},slab{slb}B,{int(tm) * 4}frag,{int(tn) * 16}ch>"
     m = re.search(r"wgrad(_halo)?_kernelI(DF16b|f)Li(\d+)ELi\d+E", name)
     if m:
         return f"wgrad{m.group(1) or ''}_kernel<{'bf16' if m.group(2) == 'DF16b' else 'f32'},Cd{m.group(3)}>"
@@ -34,7 +38,8 @@ def collect(d, counter):
 
 
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-out = {"_note": "bytes per launch, mean over all launches of 3 eager bench steps (B=8,S=2,bf16); fetch = 2 x FETCH_SIZE KiB "
+out = {"_meta": {"git_head": sys.argv[3] if len(sys.argv) > 3 else "unknown", "collected_by": "tools/pmc_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"},
+       "_note": "bytes per launch, mean over all launches of 3 eager bench steps (B=8,S=2,bf16); fetch = 2 x FETCH_SIZE KiB "
                 "(gfx950 half-count correction), write = WRITE_SIZE KiB; split-K configurations are counted with their finish pass excluded"}
 for k in sorted(set(fetch) & set(write)):
     f = 2.0 * 1024.0 * sum(fetch[k]) / len(fetch[k])
