@@ -1354,14 +1354,18 @@ bool plan_pconv(const ast_gather_t& g, int dtype, PconvPlan& pp, int& slb, int& 
   const int max_px = 256 * PC_MAXPL / cpp;                        // patch pixels a workgroup's loader covers
   double best = 0.0;
   pp.rows = 0; pp.tm = 2;
-  for (int twf = 1; twf <= 8; twf *= 2) {                         // 8 fragments per workgroup: 8x16, 4x32, 2x64, 1x128 pixels
-    const int th = 8 / twf, twp = twf * 16;
-    const int ph = th + (dhmax - dhmin), pw = twp + (dwmax - dwmin);
-    if (ph * pw > max_px) continue;
-    const int tiles_h = (g.Hm + th - 1) / th, tiles_w = (g.Wm + twp - 1) / twp;
-    const double eff = (double)g.Hm * g.Wm / ((double)tiles_h * tiles_w * 128.0) - 1e-3 * (ph * pw) / 180.0;   // ties: smaller patch
-    if (eff > best) { best = eff; pp.TH = th; pp.TWF = twf; pp.PH = ph; pp.PW = pw; pp.tiles_h = tiles_h; pp.tiles_w = tiles_w; }
-  }
+  // 2-D tiles of 8 fragments (8x16, 4x32, 2x64, 1x128 pixels); thin layers (64-byte pixels: K = 9 x 32 channels, 36 MFMAs per
+  // wave and tile) take 16 fragments (16x16 ...) so that the per-workgroup prologue / epilogue is paid half as often
+  for (int nf = (slb == 64 ? 16 : 8); nf >= 8; nf -= 8)
+    for (int twf = 1; twf <= nf; twf *= 2) {
+      const int th = nf / twf, twp = twf * 16;
+      const int ph = th + (dhmax - dhmin), pw = twp + (dwmax - dwmin);
+      if (ph * pw > max_px) continue;
+      const int tiles_h = (g.Hm + th - 1) / th, tiles_w = (g.Wm + twp - 1) / twp;
+      if (nf == 16 && (long)g.N * tiles_h * tiles_w < 1024) continue;            // only where the grid stays full
+      const double eff = (double)g.Hm * g.Wm / ((double)tiles_h * tiles_w * nf * 16.0) - 1e-3 * (ph * pw) / 180.0 + (nf == 16 ? 0.03 : 0.0);
+      if (eff > best) { best = eff; pp.tm = nf / 4; pp.TH = th; pp.TWF = twf; pp.PH = ph; pp.PW = pw; pp.tiles_h = tiles_h; pp.tiles_w = tiles_w; }
+    }
   // narrow images (the deep layers: 18x38, 9x19 pixels): TH full-width rows per workgroup, 8 or 12 fragments
   for (int nf = 8; nf <= 12; nf += 4)
     for (int th = 1; th * g.Wm <= nf * 16 && th <= g.Hm; ++th) {
@@ -1597,6 +1601,7 @@ extern "C" int ast_igemm_bn(const void* src, const void* wgt, const float* bias,
         if (slb == 128 && pp.tm == 2) { if (tn == 4) AST_PC(128, 2, 4); AST_PC(128, 2, 2); }
         if (slb == 128) { if (tn == 4) AST_PC(128, 3, 4); AST_PC(128, 3, 2); }
         if (pp.tm == 2) { if (tn == 4) AST_PC(64, 2, 4); AST_PC(64, 2, 2); }
+        if (pp.tm == 4) { if (tn == 4) AST_PC(64, 4, 4); AST_PC(64, 4, 2); }
         if (tn == 4) AST_PC(64, 3, 4); AST_PC(64, 3, 2);
       });
 #undef AST_PC
