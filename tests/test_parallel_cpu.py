@@ -27,7 +27,7 @@ def _worker(rank, world, port, q):
     flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
     parallel.allreduce_mean_(flat, world, lambda t, s: t.mul_(s))
     tmax = parallel.max_over_ranks(float(rank + 1), "cpu")
-    q.put((rank, flat.clone(), tmax))
+    q.put((rank, flat.tolist(), tmax))            # plain lists: a tensor travels as a shared-memory handle that dies with the worker
     dist.barrier()
     dist.destroy_process_group()
 
@@ -47,7 +47,7 @@ def test_flat_gradient_mean_gloo_world2():
         assert p.exitcode == 0
     want = torch.arange(1000, dtype=torch.float32) * 1.5
     for rank, flat, tmax in res:
-        assert torch.allclose(flat, want)
+        assert torch.allclose(torch.tensor(flat), want)
         assert tmax == 2.0
 
 
@@ -63,7 +63,7 @@ def _gather_worker(rank, world, port, q):
     w = torch.linspace(0.5, 2.0, B).view(B, 1) * (rank + 1)          # a rank-dependent loss, to see the sum
     (g * w).sum().backward()
     labels = parallel.global_labels(torch.tensor([0, 0, 1, 1]), world)
-    q.put((rank, g.detach().clone(), x.grad.clone(), rows, labels))
+    q.put((rank, g.detach().tolist(), x.grad.tolist(), rows, labels.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -85,7 +85,7 @@ def test_gather_rows_autograd_gloo_world2():
     glob = torch.arange(40, dtype=torch.float32).view(8, 5)
     wsum = torch.linspace(0.5, 2.0, 8).view(8, 1) * 3.0             # (rank 0: x1) + (rank 1: x2)
     for rank, g, grad, rows, labels in res:
-        assert torch.equal(g, glob)
-        assert torch.allclose(grad, wsum[rows].expand(-1, 5))
-        assert labels.tolist() == [0, 0, 0, 0, 1, 1, 1, 1]
+        assert torch.equal(torch.tensor(g), glob)
+        assert torch.allclose(torch.tensor(grad), wsum[rows].expand(-1, 5))
+        assert labels == [0, 0, 0, 0, 1, 1, 1, 1]
     assert parallel.global_row_order(8, 2) == [(0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (0, 3), (1, 2), (1, 3)]
