@@ -253,15 +253,22 @@ def convT_bn_act(x, pw, k, stride, pad, out_pad, bn: nn.BatchNorm2d, training, r
 
 
 def res_head(x, p1, pd, stride, training):
-    """(conv1(x), shortcut_conv(x), statistics table of conv1's output or None) -- see ops.ResHeadFn."""
+    """(conv1(x), shortcut_conv(x), BatchNorm statistics table of conv1's output or None, per-image InstanceNorm sums of the
+    shortcut's output or None) -- see ops.ResHeadFn."""
     stats = None
     if training and config.fused_bn_stats:
         N, H, W, Cs = x.shape
         g, _ = ops.gather_direct(N, H, W, Cs, p1.Cop, 3, stride, 1)
         if ops.stats_fusable(g, ops.dcode(x.dtype)):
             stats = ops._clean_scratch(ops.STAT_SLOTS * p1.Cop * 2, x.device, tag="bn-stats")
-    c1, idn = ops.ResHeadFn.apply(x, p1.weight, pd.weight, p1, pd, stride, stats)
-    return c1, idn, stats
+    in_stats = None
+    if training and config.fused_bn_stats:
+        N, H, W, Cs = x.shape
+        gd, _ = ops.gather_direct(N, H, W, Cs, pd.Cop, 1, stride, 0)
+        if ops.in_stats_fusable(gd, ops.dcode(x.dtype)):
+            in_stats = ops._clean_scratch(N * pd.Cop * 2, x.device, tag="in-stats")
+    c1, idn = ops.ResHeadFn.apply(x, p1.weight, pd.weight, p1, pd, stride, stats, in_stats)
+    return c1, idn, stats, in_stats
 
 
 def conv_bn_act(x, pw, k, stride, pad, bn: nn.BatchNorm2d, training, relu=True):

@@ -126,7 +126,15 @@ class BNLink:
         self.relu, self.filled = True, False
 
 
-def _igemm(src, wgt, bias, dst, g, flags=0, stats=None, bn=None):
+def in_stats_fusable(g, dt):
+    """True when ast_igemm can add per-IMAGE statistics of its output (flags bits 3 + 6): gathered or patch kernel, no split-K."""
+    import ctypes
+    out = (ctypes.c_int32 * 5)()
+    check(lib().ast_igemm_plan(g, dt, ctypes.byref(out)), "ast_igemm_plan")
+    return out[2] != 0 and _ws_need(g, dt) == 0
+
+
+def _igemm(src, wgt, bias, dst, g, flags=0, stats=None, bn=None, per_image=False):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -138,7 +146,7 @@ def _igemm(src, wgt, bias, dst, g, flags=0, stats=None, bn=None):
     else:
         if stats is not None:                   # [64][Cd][2] slots filled by the epilogue (flags bit 3); never with split-K
             assert need == 0 and flags == 0
-            ws, need, flags = stats, stats.numel(), 8
+            ws, need, flags = stats, stats.numel(), (8 | 64 if per_image else 8)
         else:
             ws = _clean_scratch(need, src.device) if need > 0 else None    # persistent, handed back zeroed by the finish pass
             flags |= 4 if need > 0 else 0
@@ -263,7 +271,7 @@ class ResHeadFn(torch.autograd.Function):
     first one's result by the GEMM epilogue (flags bit 0) instead of an ATen add over the activation map."""
 
     @staticmethod
-    def forward(ctx, x, w1, wd, pw1: PackedWeight, pwd: PackedWeight, stride, stats):
+    def forward(ctx, x, w1, wd, pw1: PackedWeight, pwd: PackedWeight, stride, stats, in_stats=None):
         N, H, W, Cs = x.shape
         g1, (Ho, Wo) = gather_direct(N, H, W, Cs, pw1.Cop, 3, stride, 1)
         gd, (Hd, Wd) = gather_direct(N, H, W, Cs, pwd.Cop, 1, stride, 0)
@@ -271,7 +279,7 @@ class ResHeadFn(torch.autograd.Function):
         c1 = torch.empty((N, Ho, Wo, pw1.Cop), dtype=x.dtype, device=x.device)
         idn = torch.empty((N, Ho, Wo, pwd.Cop), dtype=x.dtype, device=x.device)
         _igemm(x, pw1.wf, pw1.bias_ptr_tensor(), c1, g1, stats=stats)
-        _igemm(x, pwd.wf, pwd.bias_ptr_tensor(), idn, gd)
+        _igemm(x, pwd.wf, pwd.bias_ptr_tensor(), idn, gd, stats=in_stats, per_image=in_stats is not None)   # [N][C][2] InstanceNorm sums
         ctx.save_for_backward(x)
         ctx.pws, ctx.geoms, ctx.stride = (pw1, pwd), (g1, gd), stride
         return c1, idn
@@ -296,7 +304,7 @@ class ResHeadFn(torch.autograd.Function):
             for g in gathers_transposed(N, Ho, Wo, pwd.Cop, H, W, Cs, 1, stride, 0):
                 if g.ntaps > 0:                  # a 1x1 stride-s conv reaches one output-parity class only
                     _igemm(didn, pwd.wb, None, dx, g, flags=1)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
 class ConvT2dFn(torch.autograd.Function):
@@ -656,7 +664,7 @@ class ResTailFn(torch.autograd.Function):
     (style_encoder.py:76-83) as one elementwise pass over both branches."""
 
     @staticmethod
-    def forward(ctx, c2, ds, g1, b1, g2, b2, bn, inn, training, stats=None):
+    def forward(ctx, c2, ds, g1, b1, g2, b2, bn, inn, training, stats=None, in_stats=None):
         N, H, W, C = c2.shape
         Creal = g1.numel()
         if training:
@@ -664,7 +672,9 @@ class ResTailFn(torch.autograd.Function):
         else:
             m1, r1, s1, f1 = _finalize(None, N, H * W, C, Creal, False, g1, b1, bn.running_mean, bn.running_var,
                                        True, bn.eps, c2.device)
-        m2, r2, s2, f2 = _finalize(_stats(ds), N, H * W, C, Creal, True, g2, b2, None, None, False, inn.eps, c2.device)
+        # InstanceNorm sums of the shortcut: from the shortcut convolution's epilogue when it could add them, else one pass
+        m2, r2, s2, f2 = _finalize(in_stats if in_stats is not None else _stats(ds), N, H * W, C, Creal, True, g2, b2, None, None, False,
+                                   inn.eps, c2.device)
         y = torch.empty_like(c2)
         check(lib().ast_affine_act(ptr(c2), ptr(s1), ptr(f1), ptr(ds), ptr(s2), ptr(f2), ptr(y), N, H * W, C, 1,
                                    dcode(c2.dtype), stream()), "ast_affine_act")
@@ -699,7 +709,7 @@ class ResTailFn(torch.autograd.Function):
         dc2, dds = torch.empty_like(c2), torch.empty_like(ds)
         check(lib().ast_norm_bwd_apply_pre(ptr(dy), ptr(y), ptr(c2), ptr(ds), ptr(k1), ptr(k2), ptr(dc2), ptr(dds), N, H * W,
                                            C, 1, dcode(c2.dtype), *coef, stream()), "ast_norm_bwd_apply")
-        return dc2, dds, None, None, None, None, None, None, None, None
+        return dc2, dds, None, None, None, None, None, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -59,11 +59,11 @@ class ResBlock(nn.Module):
 
     def run(self, x, training):
         p1, p2, pd = self._pw
-        c1, idn, c1_stats = L.res_head(x, p1, pd, self.stride, training)
+        c1, idn, c1_stats, in_stats = L.res_head(x, p1, pd, self.stride, training)
         h = L.bn_act(c1, self.bn1, training, True, c1_stats)
         c2, c2_stats = L.conv_with_stats(h, p2, 3, 1, 1, training)
         inn = self.downsample[1]
-        return ops.ResTailFn.apply(c2, idn, self.bn2.weight, self.bn2.bias, inn.weight, inn.bias, self.bn2, inn, training, c2_stats)
+        return ops.ResTailFn.apply(c2, idn, self.bn2.weight, self.bn2.bias, inn.weight, inn.bias, self.bn2, inn, training, c2_stats, in_stats)
 
 
 def build_resnet(in_channels, channels_list):

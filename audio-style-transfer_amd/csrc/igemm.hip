@@ -150,7 +150,7 @@ template <int TN>
 __device__ __forceinline__ void epi_flush(float* ws, const bool bstats, const int Cd, float (&st1)[TN][4], float (&st2)[TN][4], const int tix,
                                           const int cbase, const int fr, const int fq) {
   const int KS = bstats ? 3 : 2;                               // floats per channel in the slot table
-  float* slot = ws + (size_t)(tix & 63) * Cd * KS;
+  float* slot = ws + (size_t)(tix < 0 ? ~tix : (tix & 63)) * Cd * KS;      // tix < 0: ~tix is the slot itself (per-image tables)
 #pragma unroll
   for (int i0 = 0; i0 < TN; i0 += 2) {
     // value q = ii*8 + r*2 + which (which: 0 = st1, 1 = st2) ends, summed over the 16 pixels, in lane fr = q
@@ -223,12 +223,20 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ s
   // the x-th contiguous eighth of the tiles in N-major order: its L2 then holds one slice of the weights and one
   // contiguous band of source rows (with its 3x3 halo) instead of a sample of everything.  Speed only; any
   // placement gives the same result.
-  const int MT = (M + BM - 1) / BM, NT = (g.Cd + BN - 1) / BN;
+  // flags bit 6: image-aligned tiles (no tile straddles two images), so that the fused statistics can go to per-IMAGE
+  // slots (InstanceNorm2d: style_encoder.py:69); M_end = end of the tile's image, else M
+  const int HWm_ = g.Hm * g.Wm;
+  const bool per_image = flags & 64;
+  const int MTI = (HWm_ + BM - 1) / BM;
+  const int MT = per_image ? g.N * MTI : (M + BM - 1) / BM, NT = (g.Cd + BN - 1) / BN;
   const int chunk = gridDim.x >> 3;
   const int tix = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tix >= MT * NT) return;
   const int ntile = tix / MT;
-  const int bm0 = (tix - ntile * MT) * BM, bn0 = ntile * BN;
+  const int mtile = tix - ntile * MT;
+  const int img = per_image ? mtile / MTI : 0;
+  const int bm0 = per_image ? img * HWm_ + (mtile - img * MTI) * BM : mtile * BM, bn0 = ntile * BN;
+  const int M_end = per_image ? (img + 1) * HWm_ : M;
   const int cpc = g.Cs / E;
   const int nchunks = g.ntaps * cpc;
   const int KT = (nchunks + KCH - 1) / KCH;
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ s
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int m = bm0 + r0 + RPP * i;
-    const bool valid = m < M;
+    const bool valid = m < M_end;
     const int mm = valid ? m : 0;
     const int n = fdiv(mm, HWm, rcp_hw), rem = mm - n * HWm;
     const int hm = fdiv(rem, g.Wm, rcp_w), wq = rem - hm * g.Wm;
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ s
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int m = bm0 + wm * WTM + j * 16 + fr;
-    if (m >= M) continue;
+    if (m >= M_end) continue;
     if (split) {
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
@@ -446,7 +454,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ s
     for (int i = 0; i < TN; ++i) col[i] = acc[i][j];
     epi_pixel<T, TN>(ec, g, col, m, bn0 + wn * WTN + fq * 4, st1, st2);
   }
-  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, tix, bn0 + wn * WTN, fr, fq);
+  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, per_image ? ~img : tix, bn0 + wn * WTN, fr, fq);
 }
 
 // ---- narrow layers: operands straight from L1/L2 into MFMA fragments, no LDS ----------------------------------------
@@ -1332,7 +1340,7 @@ __global__ __launch_bounds__(256) void pconv_kernel(const T* __restrict__ src, c
     for (int i = 0; i < TN; ++i) col[i] = acc[i][j];
     epi_store<T, TN>(ec, g, col, (size_t)(n * g.Hd + hm * g.dsh + g.doh) * g.Wd + (wq * g.dsw + g.dow), bn0 + fq * 4, st1, st2);
   }
-  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, tix, bn0, fr, fq);
+  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, (flags & 64) ? ~n : tix, bn0, fr, fq);      // bit 6: per-image slots (tiles never straddle images)
 }
 
 // Tile plan of the patch kernel, or false when the geometry should stay on the gathered kernel.
@@ -1511,7 +1519,8 @@ int launch_igemm_ut(const void* src, const void* wgt, const float* bias, void* d
   const int cpc = g.Cs / E;
   int shift = -1;
   if ((cpc & (cpc - 1)) == 0) { shift = 0; while ((1 << shift) < cpc) ++shift; }
-  const int tiles = ((M + BM - 1) / BM) * ((g.Cd + BN - 1) / BN);
+  const int mtiles = (flags & 64) ? g.N * ((g.Hm * g.Wm + BM - 1) / BM) : (M + BM - 1) / BM;     // bit 6: image-aligned tiles
+  const int tiles = mtiles * ((g.Cd + BN - 1) / BN);
   dim3 grid((tiles + 7) / 8 * 8, 1, p.nsplit);
   if (p.nsplit > 1 && !(flags & 4)) AST_HIP(hipMemsetAsync(ws, 0, sizeof(float) * (size_t)M * g.Cd, s));
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
@@ -1595,7 +1604,7 @@ extern "C" int ast_igemm_bn(const void* src, const void* wgt, const float* bias,
     if (plan_pconv(g, dtype, pp, slb, tn)) {
       if ((flags & 16) && ((flags & 11) || !ws || ws_floats < 64L * g.Cd * 3 || !bn_x || !bn_scale || !bn_shift))
         AST_FAIL("ast_igemm: fused BatchNorm-backward sums need plain stores, a zeroed [64][Cd][3] table and the layer's x / scale / shift");
-      if ((flags & 8) && ((flags & 3) || !ws || ws_floats < 64L * g.Cd * 2)) AST_FAIL("ast_igemm: fused channel statistics need plain stores and a zeroed [64][Cd][2] table");
+      if ((flags & 8) && ((flags & 3) || !ws || ws_floats < ((flags & 64) ? (long)g.N : 64L) * g.Cd * 2)) AST_FAIL("ast_igemm: fused channel statistics need plain stores and a zeroed [64][Cd][2] (per image: [N][Cd][2]) table");
 #define AST_PC(S_, M_, N_) return launch_pconv<T, S_, M_, N_>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s)
       AST_DISPATCH_T(dtype, {
         if (slb == 128 && pp.tm == 2) { if (tn == 4) AST_PC(128, 2, 4); AST_PC(128, 2, 2); }
@@ -1606,6 +1615,10 @@ extern "C" int ast_igemm_bn(const void* src, const void* wgt, const float* bias,
       });
 #undef AST_PC
     }
+  }
+  if (flags & 64) {
+    if (!(flags & 8) || p.nsplit > 1 || direct_ok(g, p, dtype)) AST_FAIL("ast_igemm: per-image statistics (flag 64) need flag 8 and the gathered kernel (ast_igemm_plan: kch > 0, no split)");
+    if (!ws || ws_floats < (long)g.N * g.Cd * 2) AST_FAIL("ast_igemm: per-image statistics need a zeroed [N][Cd][2] table");
   }
   if (direct_ok(g, p, dtype)) { AST_DISPATCH_T(dtype, { return dispatch_direct<T>(src, wgt, bias, dst, g, M, flags, ws, p, s); }); }
 #define AST_IG(BM_, BN_, WM_, WN_, K_) return launch_igemm<T, BM_, BN_, WM_, WN_, K_, 2, 1>(src, wgt, bias, dst, g, M, flags, ws, p, s)

@@ -59,7 +59,10 @@ typedef struct ast_gather_t {
  * [64][Cd][2] f32 table and every tile adds (sum, sum of squares) of the values it stores into slot
  * (tile index mod 64): nn.BatchNorm2d's batch statistics without a second pass over the output
  * (style_encoder.py:54-58, new_decoder.py:30-61).  Only for plans that do not split K (ast_igemm_plan)
- * and plain stores (bits 0 and 1 clear); reduce with ast_norm_finalize(N = 64, count = pixels). */
+ * and plain stores (bits 0 and 1 clear); reduce with ast_norm_finalize(N = 64, count = pixels).
+ * bit6 (with bit3): the table is [N][Cd][2] and every tile adds into the row of ITS IMAGE (tiles are laid out so that none
+ * straddles two images): nn.InstanceNorm2d's per-image statistics (style_encoder.py:69) without a pass over the output;
+ * gathered and patch kernels only (ast_igemm_plan: kch != 0), reduce with ast_norm_finalize(instance = 1). */
 int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst,
               const ast_gather_t* g, int dtype, int flags, float* ws, long ws_floats, void* stream);
 /* ast_igemm as the data-gradient GEMM that PRODUCES dy of a BatchNorm2d(+ReLU) layer (flags bit 4; bit 5: no ReLU):
