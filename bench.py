@@ -369,6 +369,10 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_roofline:
             out["roofline"] = kernel_roofline(tr, x, labels, args.dtype)
+            # whole step against the MFMA peak: SURVEY 8(d)'s 41.74 GFLOP per section forward + backward (3x convention)
+            step_flops = 41.74e9 * args.batch * args.sections
+            out["roofline"]["step_tflops"] = step_flops / (ms * 1e-3) / 1e12
+            out["roofline"]["step_frac_of_mfma_peak"] = out["roofline"]["step_tflops"] / PEAK_TFLOPS[args.dtype]
         if not args.no_cpu_baseline and args.decoder == "new":
             out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
