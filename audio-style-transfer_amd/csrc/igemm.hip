@@ -12,6 +12,7 @@
 // both, only the MFMA differs.  Weights are the MFMA "A" operand, so D[row][col]
 // has the output CHANNEL on the register index: each lane owns 4 consecutive
 // channels of one pixel and stores them with one 8/16-byte store into NHWC.
+#include <type_traits>
 #include "ast_common.h"
 #include "../../include/ast_hip.h"
 
@@ -85,9 +86,13 @@ struct EpiCtx {
 };
 
 // The same for a known destination pixel index `pix` (pixels of the dst tensor, not bytes).
-template <typename T, int TN>
-__device__ __forceinline__ void epi_store(const EpiCtx<T>& ec, const ast_gather_t& g, const f32x4 (&col)[TN], const size_t pix, const int co0,
-                                          float (&st1)[TN][4], float (&st2)[TN][4]) {
+// MODE (compile time): 0 plain, 1 fused BatchNorm forward statistics, 2 fused BatchNorm backward sums.  The callers branch ONCE
+// (wave-uniform) into the specialisation: with the three variants behind run-time flags in one body the compiler
+// if-converted parts of them and a wave issued ~60 VALU per 4-value block whatever the flags (1 015 VALU per 144 MFMAs on
+// the 64-channel patch kernel without any statistics requested).
+template <typename T, int TN, int MODE>
+__device__ __forceinline__ void epi_store_m(const EpiCtx<T>& ec, const ast_gather_t& g, const f32x4 (&col)[TN], const size_t pix, const int co0,
+                                            float (&st1)[TN][4], float (&st2)[TN][4]) {
   T* drow = ec.dst + pix * g.Cd;
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
@@ -101,14 +106,14 @@ __device__ __forceinline__ void epi_store(const EpiCtx<T>& ec, const ast_gather_
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] += b4[r];
     }
-    if (ec.stats) {
+    if constexpr (MODE == 1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float q = (float)(T)v[r];                      // the value as stored
         st1[i][r] += q; st2[i][r] += q * q;
       }
     }
-    if (ec.bstats) {
+    if constexpr (MODE == 2) {
       float xv[4];
       if constexpr (sizeof(T) == 2) {
         const bf16x4 xq = *reinterpret_cast<const bf16x4*>(ec.bn_x + pix * g.Cd + co);
@@ -130,6 +135,13 @@ __device__ __forceinline__ void epi_store(const EpiCtx<T>& ec, const ast_gather_
     }
     store4<T>(drow + co, v, ec.accumulate, ec.relu);
   }
+}
+template <typename T, int TN>
+__device__ __forceinline__ void epi_store(const EpiCtx<T>& ec, const ast_gather_t& g, const f32x4 (&col)[TN], const size_t pix, const int co0,
+                                          float (&st1)[TN][4], float (&st2)[TN][4]) {
+  if (ec.stats) epi_store_m<T, TN, 1>(ec, g, col, pix, co0, st1, st2);
+  else if (ec.bstats) epi_store_m<T, TN, 2>(ec, g, col, pix, co0, st1, st2);
+  else epi_store_m<T, TN, 0>(ec, g, col, pix, co0, st1, st2);
 }
 
 // One destination pixel m: the lane owns channels co0 + i*16 .. +3 of channel tile i (col[i] = their accumulators).
@@ -1155,8 +1167,33 @@ struct PconvPlan { int TH, TWF, PH, PW, dhmin, dwmin, tiles_h, tiles_w, nct, lds
 
 template <int SLB> __device__ __forceinline__ int pc_h(int p) { return SLB == 128 ? (p & 7) : ((p >> 1) & 3); }
 
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+__device__ __forceinline__ f32x4 pc_as_f32x4(u32x4 u) {
+  return __builtin_bit_cast(f32x4, u);            // (whole-vector casts: __builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)
+}
+// Four consecutive channels of one pixel at byte offset voff (+ compile-time imm) of a tensor of T, as f32 (zeros when out of range).
+template <typename T>
+__device__ __forceinline__ f32x4 pc_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int imm) {
+  if constexpr (sizeof(T) == 4) {
+    return pc_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(r, voff + (unsigned)imm, 0, 0));
+  } else {
+    const u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(r, voff + (unsigned)imm, 0, 0);
+    const u32x4 w{u.x << 16, u.x & 0xffff0000u, u.y << 16, u.y & 0xffff0000u};
+    return __builtin_bit_cast(f32x4, w);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void pc_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, int imm, f32x4 v) {
+  if constexpr (sizeof(T) == 4) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff + (unsigned)imm, 0, 0);
+  } else {
+    const bf16x4 q{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, q), r, voff + (unsigned)imm, 0, 0);
+  }
+}
+
 template <typename T, int SLB, int TM, int TN>
-__global__ __launch_bounds__(256) void pconv_kernel(const T* __restrict__ src, const T* __restrict__ wgt, const float* __restrict__ bias,
+__global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(const T* __restrict__ src, const T* __restrict__ wgt, const float* __restrict__ bias,
                                                     T* __restrict__ dst, const ast_gather_t g, const PconvPlan pp, const int flags,
                                                     float* __restrict__ ws, const unsigned src_bytes, const unsigned wgt_bytes,
                                                     const T* __restrict__ bn_x, const float* __restrict__ bn_scale,
@@ -1262,6 +1299,18 @@ __global__ __launch_bounds__(256) void pconv_kernel(const T* __restrict__ src, c
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // destination byte offset of (pixel of fragment j, first channel of the lane), or OOB; bias of the lane's channels
+  const unsigned dst_bytes = (unsigned)(g.N * g.Hd * g.Wd * g.Cd) * (unsigned)ES;            // < 2^31 (plan_pconv)
+  unsigned dofs[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    int ty, tx;
+    lane_pixel(j, ty, tx);
+    const int hm = hm0 + ty, wq = wm0 + tx;
+    const bool ok = ty < pp.TH && hm < g.Hm && wq < g.Wm;
+    dofs[j] = ok ? (unsigned)((((n * g.Hd + hm * g.dsh + g.doh) * g.Wd + (wq * g.dsw + g.dow)) * g.Cd + bn0 + fq * 4) * ES) : OOB;
+  }
+
   __syncthreads();                                // taptab
   const int nslab = (g.Cs * ES) / SLB;
   u32x4 wr[NWL];
@@ -1321,26 +1370,78 @@ __global__ __launch_bounds__(256) void pconv_kernel(const T* __restrict__ src, c
     }
   }
 
-  // ---- epilogue (shared with igemm_kernel): lane owns pixel fr of fragment j, channels fq*4.. of channel tile i
+  // ---- epilogue: lane owns pixel fr of fragment j, channels fq*4.. of channel tile i.  Same arithmetic as epi_store_m
+  // (igemm_kernel's), written for this kernel's fixed tile: destination offsets (dofs) were computed before the tap loop, the bias is
+  // fetched once, loads / stores are buffer instructions whose masked lanes carry an out-of-range offset (no exec-mask branches, no
+  // 64-bit address arithmetic), and the mode (plain / BatchNorm forward sums / backward sums) is a wave-uniform branch
+  // around three straight-line bodies.  (The shared epilogue cost this kernel ~70 VALU per 4-value block and a dependent
+  // bias load per block: 1 015 VALU per 144 MFMAs on the 64-channel layers.)
   const bool accumulate = flags & 1, relu = flags & 2, stats = flags & 8, bstats = flags & 16, bn_relu = !(flags & 32);
-  EpiCtx<T> ec{dst, bias, ws, bn_x, bn_scale, bn_shift, g.Hm * g.Wm, 0.f, 0.f, accumulate, relu, stats, bstats, bn_relu};
+  const __amdgpu_buffer_rsrc_t dstR = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, dst_bytes, 0x00020000);
+  f32x4 bv[TN];
+  {
+    const __amdgpu_buffer_rsrc_t biasR = __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, bias ? (unsigned)g.Cd * 4u : 0u, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) bv[i] = pc_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(biasR, (unsigned)(bn0 + fq * 4) * 4u, i * 64, 0));
+  }
   float st1[TN][4], st2[TN][4];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) { st1[i][q] = 0.f; st2[i][q] = 0.f; }
+  auto run = [&](auto mode_tag) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    const __amdgpu_buffer_rsrc_t bnxR = __builtin_amdgcn_make_buffer_rsrc((void*)bn_x, 0, MODE == 2 ? dst_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t scR = __builtin_amdgcn_make_buffer_rsrc((void*)bn_scale, 0, MODE == 2 ? (unsigned)g.Cd * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sfR = __builtin_amdgcn_make_buffer_rsrc((void*)bn_shift, 0, MODE == 2 ? (unsigned)g.Cd * 4u : 0u, 0x00020000);
+    // channel tile outermost: the coefficient / old-value / BN-input loads of one channel tile (all TM pixels) are issued
+    // together and waited for once, and only one tile's worth of them is live
 #pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    int ty, tx;
-    lane_pixel(j, ty, tx);
-    const int hm = hm0 + ty, wq = wm0 + tx;
-    if (ty >= pp.TH || hm >= g.Hm || wq >= g.Wm) continue;
-    f32x4 col[TN];
+    for (int i = 0; i < TN; ++i) {
+      if (bn0 + i * 16 >= g.Cd) continue;           // wave-uniform (Cd % 16 == 0: plan_pconv)
+      f32x4 sc4, sf4, old[TM], xq[TM];
+      if constexpr (MODE == 2) {
+        sc4 = pc_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(scR, (unsigned)(bn0 + fq * 4) * 4u, i * 64, 0));
+        sf4 = pc_as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(sfR, (unsigned)(bn0 + fq * 4) * 4u, i * 64, 0));
 #pragma unroll
-    for (int i = 0; i < TN; ++i) col[i] = acc[i][j];
-    epi_store<T, TN>(ec, g, col, (size_t)(n * g.Hd + hm * g.dsh + g.doh) * g.Wd + (wq * g.dsw + g.dow), bn0 + fq * 4, st1, st2);
-  }
-  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, (flags & 64) ? ~n : tix, bn0, fr, fq);      // bit 6: per-image slots (tiles never straddle images)
+        for (int j = 0; j < TM; ++j) xq[j] = pc_load4<T>(bnxR, dofs[j], i * 16 * ES);
+      }
+      if (accumulate) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) old[j] = pc_load4<T>(dstR, dofs[j], i * 16 * ES);
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const bool live = dofs[j] != OOB;           // lanes past the tile / image computed on a valid patch address: drop them
+        f32x4 v = acc[i][j] + bv[i];
+        if constexpr (MODE == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float q = live ? (float)(T)v[r] : 0.f;                     // the value as stored
+            st1[i][r] += q; st2[i][r] = __builtin_fmaf(q, q, st2[i][r]);
+          }
+        }
+        if constexpr (MODE == 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float q = (float)(T)v[r];
+            const float dz = (live && (!bn_relu || __builtin_fmaf(xq[j][r], sc4[r], sf4[r]) > 0.f)) ? q : 0.f;
+            st1[i][r] += dz; st2[i][r] = __builtin_fmaf(dz, xq[j][r], st2[i][r]);
+          }
+        }
+        if (accumulate) v += old[j];
+        if (relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        pc_store4<T>(dstR, dofs[j], i * 16 * ES, v);
+      }
+    }
+  };
+  if (stats) run(std::integral_constant<int, 1>{});
+  else if (bstats) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 0>{});
+  if (stats || bstats) epi_flush<TN>(ws, bstats, g.Cd, st1, st2, (flags & 64) ? ~n : tix, bn0, fr, fq);      // bit 6: per-image slots (tiles never straddle images)
 }
 
 // Tile plan of the patch kernel, or false when the geometry should stay on the gathered kernel.
@@ -1351,7 +1452,8 @@ bool plan_pconv(const ast_gather_t& g, int dtype, PconvPlan& pp, int& slb, int& 
   const int rowb = g.Cs * ES;
   if (rowb % 64) return false;
   slb = (rowb % 128 == 0) ? 128 : 64;
-  if (g.Cd < 32) return false;
+  if (g.Cd < 32 || g.Cd % 16) return false;
+  if ((double)g.N * g.Hd * g.Wd * g.Cd * ES >= 2147483648.0) return false;      // 32-bit destination offsets, OOB sentinel 2^31
   tn = g.Cd >= 64 ? 4 : 2;
   int dhmin = 64, dhmax = -64, dwmin = 64, dwmax = -64;
   for (int t = 0; t < g.ntaps; ++t) {
