@@ -1163,7 +1163,23 @@ int launch_wgrad_halo(const void* dy, const void* src, float* dw, const ast_gath
 // fragment base pixel (brute-forced over all bases), which the per-tap shifts need.
 // ---------------------------------------------------------------------------
 constexpr int PC_MAXPL = 8;          // patch chunks (16 B) per thread
-struct PconvPlan { int TH, TWF, PH, PW, dhmin, dwmin, tiles_h, tiles_w, nct, lds, rows, tm; float rcp_nct, rcp_per_img, rcp_tiles_w, rcp_pw, rcp_twf; };
+
+// In-kernel phase stamps (debug build only: `make stamps` -> libast_hip_stamps.so, read by tools/pconv_stamps.py): thread 0 of
+// every workgroup records the shader clock at the phase boundaries of the patch kernel.
+#ifdef AST_STAMPS
+__device__ unsigned long long ast_stamps[16384 * 8];
+#define PC_STAMP(k) do { if (threadIdx.x == 0 && tix < 16384) ast_stamps[tix * 8 + (k)] = (k) >= 6 ? wall_clock64() : __builtin_readcyclecounter(); } while (0)
+#else
+#define PC_STAMP(k) do { } while (0)
+#endif
+struct PconvPlan { int TH, TWF, PH, PW, dhmin, dwmin, tiles_h, tiles_w, nct, lds, rows, tm; unsigned m_nct, m_per_img, m_tiles_w, m_pw20, m_twf, m_twf20; unsigned long long tapq[3]; };
+// Division by a run-time constant d through m = ceil(2^32 / d): floor(n / d) = umulhi(n, m), exact while n * d < 2^32
+// (plan_pconv checks).  On wave-uniform operands it is ONE scalar instruction (s_mul_hi_u32); the float-reciprocal fdiv the
+// gathered kernels use is ~12 VALU even for scalars, and the four waves of a SIMD all run this prologue at the same time.
+__host__ __device__ __forceinline__ unsigned pc_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+__device__ __forceinline__ int pc_div(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
+// per-lane operands below 2^11 by divisors below 2^9: full-rate 24-bit multiply, m20 = ceil(2^20 / d)
+__device__ __forceinline__ int pc_div20(int n, unsigned m20) { return (int)(__umul24((unsigned)n, m20) >> 20); }
 
 template <int SLB> __device__ __forceinline__ int pc_h(int p) { return SLB == 128 ? (p & 7) : ((p >> 1) & 3); }
 
@@ -1208,7 +1224,6 @@ __global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(cons
   extern __shared__ __attribute__((aligned(16))) unsigned char pl[];
   const int patch_bytes = pp.PH * pp.PW * SLB;
   unsigned char* wbuf = pl + patch_bytes;        // two stages of BN x SLB
-  int* taptab = reinterpret_cast<int*>(wbuf + 2 * BN * SLB);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -1216,10 +1231,10 @@ __global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(cons
   const int tix = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   const int per_img = pp.tiles_h * pp.tiles_w;
   if (tix >= g.N * per_img * pp.nct) return;
-  // (reciprocal division: three integer divisions by run-time values cost ~100 VALU per wave, as much as two taps)
-  const int st = fdiv(tix, pp.nct, pp.rcp_nct), ct = tix - st * pp.nct;      // channel tiles of one spatial tile are neighbours (same patch in L2)
-  const int n = fdiv(st, per_img, pp.rcp_per_img), r = st - n * per_img;
-  const int th = fdiv(r, pp.tiles_w, pp.rcp_tiles_w), tw = r - th * pp.tiles_w;
+  PC_STAMP(0); PC_STAMP(7);
+  const int st = pc_div(tix, pp.nct, pp.m_nct), ct = tix - st * pp.nct;      // channel tiles of one spatial tile are neighbours (same patch in L2)
+  const int n = pc_div(st, per_img, pp.m_per_img), r = st - n * per_img;
+  const int th = pc_div(r, pp.tiles_w, pp.m_tiles_w), tw = r - th * pp.tiles_w;
   const int TWP = pp.rows ? g.Wm : pp.TWF * 16;
   const int hm0 = th * pp.TH, wm0 = tw * TWP;
   const int bn0 = ct * BN;
@@ -1227,36 +1242,32 @@ __global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(cons
   const __amdgpu_buffer_rsrc_t srcR = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wgtR = __builtin_amdgcn_make_buffer_rsrc((void*)wgt, 0, wgt_bytes, 0x00020000);
 
-#pragma unroll
-  for (int t = 0; t < AST_MAX_TAPS; ++t)
-    if (tid == t) {
-      int dh, dw, wt;
-      decode_tap(g.tap[t], dh, dw, wt);
-      taptab[t] = (dh - pp.dhmin) * pp.PW + (dw - pp.dwmin);       // patch pixel offset of the tap
-      taptab[16 + t] = wt * g.Cs * ES;                             // byte offset of the tap's weight slice in a weight row
-    }
+  // Tap t: patch pixel offset (12 bits) and weight-slice index (4 bits), packed four to a 64-bit kernel argument by
+  // plan_pconv: scalar shifts instead of an LDS table (whose set-up was nine branchy blocks, each behind its own s_load,
+  // plus a barrier before the first load could issue).
+  auto tap_entry = [&](int t) __attribute__((always_inline)) -> unsigned {
+    const unsigned long long q = t < 4 ? pp.tapq[0] : (t < 8 ? pp.tapq[1] : pp.tapq[2]);
+    return (unsigned)(q >> ((t & 3) * 16)) & 0xffffu;
+  };
+  const unsigned wslice = (unsigned)(g.Cs * ES);  // bytes of one tap's slice of a weight row
 
   // ---- loader descriptors (this workgroup's tile: fixed for the whole kernel).  Chunk i of thread t is chunk t % CPP of
-  // patch pixel t / CPP + i * (256 / CPP): the pixel coordinates advance incrementally (one division in all).
+  // patch pixel t / CPP + i * PSTEP.  PSTEP is a multiple of 8, so the swizzle term H(pixel) is the same for all of a
+  // thread's chunks: their LDS addresses are l0 + i * PSTEP * SLB (compile-time immediates).
+  constexpr int PSTEP = 256 / CPP;               // patch pixels between a thread's consecutive chunks
+  const int npix = pp.PH * pp.PW;
+  const int p0 = tid / CPP;
+  const int l0 = p0 * SLB + (((tid % CPP) ^ pc_h<SLB>(p0)) << 4);
   unsigned goff[PC_MAXPL];
-  int lofs[PC_MAXPL];
   {
-    constexpr int PSTEP = 256 / CPP;             // patch pixels between a thread's consecutive chunks
-    const int npix = pp.PH * pp.PW;
-    const int c = tid % CPP;
-    int pix = tid / CPP;
-    int py = fdiv(pix, pp.PW, pp.rcp_pw), px = pix - py * pp.PW;
-    const int gbase = (((n * g.Hs + hs_org) * g.Ws + ws_org) * g.Cs) * ES + c * 16;
+    const int rowb = g.Cs * ES;
+    const unsigned gbase = (unsigned)(((n * g.Hs + hs_org) * g.Ws + ws_org) * rowb + (tid % CPP) * 16);
 #pragma unroll
     for (int i = 0; i < PC_MAXPL; ++i) {
-      const bool in_patch = pix < npix;
-      const bool in_img = (unsigned)(hs_org + py) < (unsigned)g.Hs && (unsigned)(ws_org + px) < (unsigned)g.Ws;
-      goff[i] = (in_patch && in_img) ? (unsigned)(gbase + ((py * g.Ws + px) * g.Cs) * ES) : OOB;
-      lofs[i] = in_patch ? pix * SLB + ((c ^ pc_h<SLB>(pix)) << 4) : -1;
-      pix += PSTEP; px += PSTEP;
-      if (px >= pp.PW) { px -= pp.PW; ++py; }    // PW >= 16 + halo and PSTEP <= 64: at most four wraps
-      if (px >= pp.PW) { px -= pp.PW; ++py; }
-      if (PSTEP > 32) { if (px >= pp.PW) { px -= pp.PW; ++py; } if (px >= pp.PW) { px -= pp.PW; ++py; } }
+      const int pix = p0 + i * PSTEP;
+      const int py = pc_div20(pix, pp.m_pw20), px = pix - (int)__umul24(py, pp.PW);
+      const bool ok = pix < npix && (unsigned)(hs_org + py) < (unsigned)g.Hs && (unsigned)(ws_org + px) < (unsigned)g.Ws;
+      goff[i] = ok ? gbase + __umul24(__umul24(py, g.Ws) + px, rowb) : OOB;
     }
   }
   unsigned woff[NWL];
@@ -1280,9 +1291,9 @@ __global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(cons
     const int f = __builtin_amdgcn_readfirstlane(wave) * TM + j;      // wave-uniform: scalar arithmetic
     if (pp.rows) {
       const int q = f * 16 + fr;
-      ty = fdiv(q, g.Wm, pp.rcp_twf); tx = q - ty * g.Wm;             // rcp_twf = 1 / Wm in this mode
+      ty = pc_div20(q, pp.m_twf20); tx = q - ty * g.Wm;               // m_twf20 = ceil(2^20 / Wm) in this mode
     } else {
-      ty = fdiv(f, pp.TWF, pp.rcp_twf); tx = (f - ty * pp.TWF) * 16 + fr;
+      ty = pc_div(f, pp.TWF, pp.m_twf); tx = (f - ty * pp.TWF) * 16 + fr;
     }
   };
   int pb[TM];                                     // patch pixel of this lane's output pixel (before the tap offset)
@@ -1311,7 +1322,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(cons
     dofs[j] = ok ? (unsigned)((((n * g.Hd + hm * g.dsh + g.doh) * g.Wd + (wq * g.dsw + g.dow)) * g.Cd + bn0 + fq * 4) * ES) : OOB;
   }
 
-  __syncthreads();                                // taptab
+  PC_STAMP(1);
   const int nslab = (g.Cs * ES) / SLB;
   u32x4 wr[NWL];
   for (int s = 0; s < nslab; ++s) {
@@ -1320,27 +1331,28 @@ __global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(cons
       u32x4 pr[PC_MAXPL];
 #pragma unroll
       for (int i = 0; i < PC_MAXPL; ++i) pr[i] = __builtin_amdgcn_raw_buffer_load_b128(srcR, goff[i] + sb, 0, 0);
-      const unsigned w0 = (unsigned)__builtin_amdgcn_readfirstlane(taptab[16]) + sb;
+      const unsigned w0 = (tap_entry(0) >> 12) * wslice + sb;
 #pragma unroll
       for (int k = 0; k < NWL; ++k) wr[k] = __builtin_amdgcn_raw_buffer_load_b128(wgtR, woff[k] + w0, 0, 0);
       // (the previous slab's last tap ended with a barrier: every read of the patch and of stage 0 is done)
 #pragma unroll
       for (int i = 0; i < PC_MAXPL; ++i)
-        if (lofs[i] >= 0) *reinterpret_cast<u32x4*>(pl + lofs[i]) = pr[i];
+        if (p0 + i * PSTEP < npix) *reinterpret_cast<u32x4*>(pl + l0 + i * (PSTEP * SLB)) = pr[i];
 #pragma unroll
       for (int k = 0; k < NWL; ++k)
         if (wl[k] >= 0) *reinterpret_cast<u32x4*>(wbuf + wl[k]) = wr[k];
     }
     __syncthreads();
+    if (s == 0) PC_STAMP(2);
     for (int t = 0; t < g.ntaps; ++t) {
       const int cur = t & 1;
       const bool more = t + 1 < g.ntaps;
       if (more) {
-        const unsigned wn = (unsigned)__builtin_amdgcn_readfirstlane(taptab[16 + t + 1]) + sb;
+        const unsigned wn = (tap_entry(t + 1) >> 12) * wslice + sb;
 #pragma unroll
         for (int k = 0; k < NWL; ++k) wr[k] = __builtin_amdgcn_raw_buffer_load_b128(wgtR, woff[k] + wn, 0, 0);
       }
-      const int toff = __builtin_amdgcn_readfirstlane(taptab[t]);
+      const int toff = (int)(tap_entry(t) & 0xfffu);
       const unsigned char* wcur = wbuf + cur * (BN * SLB);
       int xa[TM];
 #pragma unroll
@@ -1370,6 +1382,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(cons
     }
   }
 
+  PC_STAMP(3);
   // ---- epilogue: lane owns pixel fr of fragment j, channels fq*4.. of channel tile i.  Same arithmetic as epi_store_m
   // (igemm_kernel's), written for this kernel's fixed tile: destination offsets (dofs) were computed before the tap loop, the bias is
   // fetched once, loads / stores are buffer instructions whose masked lanes carry an out-of-range offset (no exec-mask branches, no
@@ -1441,8 +1454,15 @@ __global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(cons
   if (stats) run(std::integral_constant<int, 1>{});
   else if (bstats) run(std::integral_constant<int, 2>{});
   else run(std::integral_constant<int, 0>{});
+  PC_STAMP(4);
   if (stats || bstats) epi_flush<TN>(ws, bstats, g.Cd, st1, st2, (flags & 64) ? ~n : tix, bn0, fr, fq);      // bit 6: per-image slots (tiles never straddle images)
+  PC_STAMP(5); PC_STAMP(6);
 }
+#ifdef AST_STAMPS
+extern "C" int ast_debug_read_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ast_stamps), (size_t)n * 8 * sizeof(unsigned long long));
+}
+#endif
 
 // Tile plan of the patch kernel, or false when the geometry should stay on the gathered kernel.
 bool plan_pconv(const ast_gather_t& g, int dtype, PconvPlan& pp, int& slb, int& tn) {
@@ -1490,9 +1510,20 @@ bool plan_pconv(const ast_gather_t& g, int dtype, PconvPlan& pp, int& slb, int& 
   const long spatial = (long)g.N * pp.tiles_h * pp.tiles_w;
   if (tn == 4 && spatial * ((g.Cd + 63) / 64) < 200) tn = 2;      // few tiles: 32-channel tiles double the workgroups
   pp.nct = (g.Cd + tn * 16 - 1) / (tn * 16);
-  pp.lds = pp.PH * pp.PW * slb + 2 * tn * 16 * slb + 160;
-  pp.rcp_nct = 1.0f / (float)pp.nct; pp.rcp_per_img = 1.0f / (float)(pp.tiles_h * pp.tiles_w); pp.rcp_tiles_w = 1.0f / (float)pp.tiles_w;
-  pp.rcp_pw = 1.0f / (float)pp.PW; pp.rcp_twf = 1.0f / (float)(pp.rows ? g.Wm : pp.TWF);
+  pp.lds = pp.PH * pp.PW * slb + 2 * tn * 16 * slb;
+  pp.tapq[0] = pp.tapq[1] = pp.tapq[2] = 0;
+  for (int t = 0; t < g.ntaps; ++t) {
+    const int dh = (g.tap[t] & 255) - 64, dw = ((g.tap[t] >> 8) & 255) - 64, wt = g.tap[t] >> 16;
+    const int toff = (dh - dhmin) * pp.PW + (dw - dwmin);      // patch pixel offset of the tap
+    if (toff >= 4096 || wt >= 16) return false;
+    pp.tapq[t >> 2] |= (unsigned long long)(toff | (wt << 12)) << ((t & 3) * 16);
+  }
+  pp.m_nct = pc_magic(pp.nct); pp.m_per_img = pc_magic(pp.tiles_h * pp.tiles_w); pp.m_tiles_w = pc_magic(pp.tiles_w);
+  pp.m_twf = pc_magic(pp.TWF);
+  pp.m_pw20 = (unsigned)(((1u << 20) + pp.PW - 1) / pp.PW); pp.m_twf20 = (unsigned)(((1u << 20) + g.Wm - 1) / g.Wm);
+  // exactness of the multiply-shift divisions (see pc_div / pc_div20) and 24-bit operands of the address products
+  if ((double)g.N * pp.tiles_h * pp.tiles_w * pp.nct * std::max(pp.nct, pp.tiles_h * pp.tiles_w) >= 4294967296.0) return false;
+  if (pp.PW >= 512 || g.Wm >= 512 || g.Ws >= (1 << 12) || g.Hs >= (1 << 12) || g.Cs * ES >= (1 << 13)) return false;
   const char* mt = getenv("AST_PCONV_MIN_TILES");
   const long min_tiles = mt ? atol(mt) : 192;
   if (spatial * pp.nct < min_tiles) return false;                 // under-filled grids keep the K-split plans
