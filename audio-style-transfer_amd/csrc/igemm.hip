@@ -1486,16 +1486,36 @@ bool plan_pconv(const ast_gather_t& g, int dtype, PconvPlan& pp, int& slb, int& 
   pp.rows = 0; pp.tm = 2;
   // 2-D tiles of 8 fragments (8x16, 4x32, 2x64, 1x128 pixels); thin layers (64-byte pixels: K = 9 x 32 channels, 36 MFMAs per
   // wave and tile) take 16 fragments (16x16 ...) so that the per-workgroup prologue / epilogue is paid half as often
-  for (int nf = (slb == 64 ? 16 : 8); nf >= 8; nf -= 8)
+  // 2-D tiles of 8, 12 or 16 fragments (8x16, 4x32, ... pixels).  More fragments per wave = fewer LDS fragment reads per
+  // MFMA ((TM + TN) / (TM * TN): the tap loop runs at the LDS read rate with four 8-fragment workgroups on a CU) and the
+  // prologue / epilogue paid less often, but fewer workgroups per CU (LDS, registers) and a coarser last round:
+  //  * 128-byte slabs: 8 fragments; 12 when the 8-fragment grid fits one round of 4 workgroups per CU anyway (measured on
+  //    the 128-channel layer: 25.9 -> 23.4 us; the 64-channel layer, two rounds either way, 27.9 -> 28.9 us);
+  //  * 64-byte slabs (32 channels: K = 9 x 32, 36 MFMAs per wave and 8-fragment tile): 16 where the grid stays full.
+  const char* nfe = getenv("AST_PCONV_NF");                    // experiments: force the fragment count of 2-D tiles
+  struct Cand { double eff; int th, twf, ph, pw, tiles_h, tiles_w; } cand[3] = {{0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0}};
+  for (int k = 0; k < 3; ++k) {
+    const int nf = 8 + 4 * k;
     for (int twf = 1; twf <= nf; twf *= 2) {
+      if (nf % twf) continue;
       const int th = nf / twf, twp = twf * 16;
       const int ph = th + (dhmax - dhmin), pw = twp + (dwmax - dwmin);
       if (ph * pw > max_px) continue;
       const int tiles_h = (g.Hm + th - 1) / th, tiles_w = (g.Wm + twp - 1) / twp;
-      if (nf == 16 && (long)g.N * tiles_h * tiles_w < 1024) continue;            // only where the grid stays full
-      const double eff = (double)g.Hm * g.Wm / ((double)tiles_h * tiles_w * nf * 16.0) - 1e-3 * (ph * pw) / 180.0 + (nf == 16 ? 0.03 : 0.0);
-      if (eff > best) { best = eff; pp.tm = nf / 4; pp.TH = th; pp.TWF = twf; pp.PH = ph; pp.PW = pw; pp.tiles_h = tiles_h; pp.tiles_w = tiles_w; }
+      const double eff = (double)g.Hm * g.Wm / ((double)tiles_h * tiles_w * nf * 16.0) - 1e-3 * (ph * pw) / 180.0;
+      if (eff > cand[k].eff) cand[k] = Cand{eff, th, twf, ph, pw, tiles_h, tiles_w};
     }
+  }
+  const int nctp = (g.Cd + tn * 16 - 1) / (tn * 16);
+  auto wgs = [&](const Cand& c) { return (long)g.N * c.tiles_h * c.tiles_w * nctp; };
+  int pick = 0;
+  if (nfe) pick = (atoi(nfe) - 8) / 4;
+  else if (slb == 64 && cand[2].eff > 0 && (long)g.N * cand[2].tiles_h * cand[2].tiles_w >= 1024 && cand[2].eff + 0.03 > cand[0].eff) pick = 2;
+  else if (slb == 128 && cand[1].eff > 0 && cand[0].eff > 0 && wgs(cand[0]) <= 1024 && wgs(cand[1]) >= 384 && cand[1].eff + 0.05 > cand[0].eff) pick = 1;
+  if (pick >= 0 && pick < 3 && cand[pick].eff > 0) {
+    const Cand& c = cand[pick];
+    best = c.eff; pp.tm = 2 + pick; pp.TH = c.th; pp.TWF = c.twf; pp.PH = c.ph; pp.PW = c.pw; pp.tiles_h = c.tiles_h; pp.tiles_w = c.tiles_w;
+  }
   // narrow images (the deep layers: 18x38, 9x19 pixels): TH full-width rows per workgroup, 8 or 12 fragments
   for (int nf = 8; nf <= 12; nf += 4)
     for (int th = 1; th * g.Wm <= nf * 16 && th <= g.Hm; ++th) {
