@@ -106,6 +106,8 @@ _SIGS = {
     "ast_cqt_octaves": ([vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, vp], i32),
     "ast_cqt_sections": ([vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "ast_resample_poly": ([vp, i32, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp], i32),
+    "ast_tok_max_ops": ([], i32),
+    "ast_tok_program": ([vp, i32, i32, i32, vp, vp, vp, vp], i32),
 }
 
 EXPORTS = tuple(_SIGS) + ("ast_last_error",)

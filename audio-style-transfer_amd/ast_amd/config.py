@@ -18,6 +18,8 @@ def set_compute_dtype(dtype):
 # the reference the fused kernels are tested against; AST_FUSED_TOKENS=0 selects it for A/B timing.
 import os as _os
 fused_tokens = _os.environ.get("AST_FUSED_TOKENS", "1") != "0"
+# transformer stacks as token programs (ast_tok_program: a few launches per stack instead of one per operator)
+tok_programs = _os.environ.get("AST_TOK_PROGRAMS", "1") != "0"
 
 # BatchNorm batch statistics accumulated in the producing conv GEMM's epilogue instead of a separate pass over its
 # output (AST_FUSED_BN_STATS=0 keeps the separate pass: the reference path for tests and A/B timing).

@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from . import layers as L
-from . import ops
+from . import config, ops, tokprog
 from .style_encoder import (CHANNELS, ResBlock, SinusoidalPositionalEncoding, _module_bank, build_resnet,
                             initialize_weights, run_resnet)  # noqa: F401
 
@@ -42,6 +42,9 @@ class ContentEncoder(nn.Module):
         if self._inp is not None:
             feat = L.linear(feat, self._inp)
         seq = L.layer_norm(self.pos_encoder(feat.view(B, S, -1)), self.norm)
-        for lyr in self._layers:
-            seq = lyr(seq, self.training)
+        if config.tok_programs and tokprog.encoder_stack_ok(seq, self._layers):
+            seq = tokprog.encoder_stack(seq, self._layers, self.training, xcd=1)
+        else:
+            for lyr in self._layers:
+                seq = lyr(seq, self.training)
         return seq

@@ -6,7 +6,7 @@ import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
 from . import layers as L
-from . import ops
+from . import config, ops, tokprog
 from .style_encoder import SinusoidalPositionalEncoding, _module_bank
 
 ENC_CH = ((2, 16, 1), (16, 32, 2), (32, 64, 2), (64, 64, 2))        # (cin, cout, stride)  new_decoder.py:29-48
@@ -127,6 +127,8 @@ class Decoder(nn.Module):
         return self._memory(content_emb, class_emb)
 
     def _stack(self, tgt, memory):
+        if config.tok_programs and tokprog.decoder_stack_ok(tgt, memory, self._layers):
+            return tokprog.decoder_stack(tgt, memory, self._layers, self.training)
         for lyr in self._layers:
             tgt = lyr(tgt, memory, self.training)
         return tgt

@@ -14,7 +14,7 @@ import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
 from . import layers as L
-from . import ops
+from . import config, ops, tokprog
 
 CHANNELS = (32, 64, 128, 256, 512, 512)
 
@@ -157,8 +157,11 @@ class StyleEncoder(nn.Module):
         if self.use_cls:
             seq = torch.cat([self.cls_token.expand(B, -1, -1), seq], dim=1)
         seq = L.layer_norm(self.pos_encoder(seq), self.norm)
-        for lyr in self._layers:
-            seq = lyr(seq, self.training)
+        if config.tok_programs and tokprog.encoder_stack_ok(seq, self._layers):
+            seq = tokprog.encoder_stack(seq, self._layers, self.training, xcd=0)
+        else:
+            for lyr in self._layers:
+                seq = lyr(seq, self.training)
         style_emb = seq[:, 0, :] if self.use_cls else seq.mean(dim=1)
         class_emb = class_prototypes(style_emb, labels) if labels is not None else None
         return style_emb, class_emb

@@ -338,6 +338,39 @@ int ast_cqt_sections(const float* cqt, int Bc, int T, int nb, const float* mean,
 int ast_resample_poly(const float* x, int B, int n, const float* kern, int orig, int nnew, int klen, int width, float* y, int m,
                       float gain, void* stream);
 
+/* ---- token programs: transformer layers in one launch (csrc/tokprog.hip) ------------------------------------------------
+ * Replaces, for the <= 64 token rows of the transformer stacks (style_encoder.py:181-191, content_encoder.py:24-26,
+ * new_decoder.py:49-51,111-119), the per-operator launches above (ast_skinny_gemm*, ast_attn_fwd_p / ast_attn_bwd_p,
+ * ast_add_drop_ln_fwd / _bwd) by ONE launch that walks a list of ops with a grid barrier between them.  All tensors are
+ * f32 row-major; an op reads what earlier ops of the same launch wrote.  ast_tok_max_ops() ops per launch at most.
+ *   AST_TOK_GEMM      y[M][N] = epi(x[M][K] w[N][K]^T): i = {M, N, K, ldx, ldw, ldy}; in = {x, w, bias?, mul_mask?, addend?};
+ *                     out = {y, drop_mask?}; flags & 1: ReLU.  epi: +bias, ReLU, dropout (p, seed; the combined ReLU &
+ *                     dropout mask goes to drop_mask), * mul_mask, + addend.  M <= 64, N % 16 == 0.
+ *   AST_TOK_ATTN_FWD  softmax(q k^T / sqrt(dh)) v per (batch, head): i = {B, H, Lq, Lk, dh, ldq, ldk, ldo}; in = {q, k, v};
+ *                     out = {o, probs (B,H,Lq,Lk)}; flags & 4: causal; p, seed: dropout on the probabilities (redrawn by _BWD).
+ *   AST_TOK_ATTN_BWD  same i; in = {dout, q, k, v, probs}; out = {dq, dk, dv}.
+ *   AST_TOK_ADLN_FWD  s = x + dropout(sub), y = LayerNorm(s): i = {rows, 256}; in = {x?, sub, gamma?, beta?};
+ *                     out = {mask?, s?, y?, mean?, rstd?}; p, seed, eps.
+ *   AST_TOK_ADLN_BWD  ds = ds_ext + LayerNorm_bwd(dy; s), dx = ds, dsub = ds * mask: i = {rows, 256};
+ *                     in = {dy?, ds_ext?, s, gamma, mean, rstd, mask?}; out = {dx?, dsub?, dgamma?, dbeta?} (+= for the last two).
+ * flags & AST_TOK_NO_BARRIER: the next op does not depend on this one (no grid barrier between them).
+ * G (<= 32) workgroups do the work (those with blockIdx % 8 == xcd of an 8 G grid); sync = 2 zeroed uint32 owned by this
+ * call chain (launches that may run concurrently need their own); *status becomes 1 if a barrier wait timed out;
+ * d_offset = the device step counter of the dropout draws (as ast_dropout_fwd). */
+enum { AST_TOK_GEMM = 1, AST_TOK_ATTN_FWD = 2, AST_TOK_ATTN_BWD = 3, AST_TOK_ADLN_FWD = 4, AST_TOK_ADLN_BWD = 5 };
+enum { AST_TOK_RELU = 1, AST_TOK_NO_BARRIER = 2, AST_TOK_CAUSAL = 4 };
+typedef struct {
+  int32_t type, flags;
+  int32_t i[8];
+  float p, eps;
+  uint64_t seed;
+  const float* in[7];
+  float* out[5];
+} ast_tok_op_t;
+int ast_tok_max_ops(void);
+int ast_tok_program(const ast_tok_op_t* ops, int nops, int G, int xcd, void* sync, int* status, const int64_t* d_offset,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,13 +14,12 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 config.set_compute_dtype(torch.bfloat16)
 dev = torch.device("cuda:0")
 tr = Trainer(TrainConfig(use_graph=False), device=dev)
-waves, x, mean, std, cm, cs = synthetic_waveform_batch(B, 2.0 * S, dev)
-tr.set_frontend(waves, mean, std, cm, cs)
-labels = torch.tensor([0] * (B // 2) + [1] * (B // 2))
+waves, x, mean, std, labels = synthetic_waveform_batch(B, 2.0 * S, dev)
+tr.set_frontend(waves, mean, std, torch.zeros(2, 84, device=dev), torch.full((2, 84), 0.25, device=dev))
 for _ in range(2):
     tr.step(x, labels)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
     tr.step(x, labels)
     torch.cuda.synchronize()
 LAUNCHING = ("aten::fill_", "aten::zero_", "aten::add_", "aten::add", "aten::mul", "aten::mul_", "aten::copy_", "aten::div", "aten::div_",
@@ -39,7 +38,11 @@ for ev in prof.events():
         if "/ast_amd/" in fr or "/oracle/" in fr or "bench.py" in fr:
             site = fr.split("/ast_amd/")[-1] if "/ast_amd/" in fr else fr
             break
-    sites[(ev.name, site)] += 1
+    else:
+        if ev.stack:
+            site = "stack: " + " <- ".join(f.split("/")[-1] for f in ev.stack[:3])
+    shp = str([tuple(x) for x in (ev.input_shapes or []) if x][:2])
+    sites[(ev.name, site + " " + shp)] += 1
 tot = sum(sites.values())
 print(f"{tot} launching ATen ops in one eager step (B={B}, S={S})")
 for (name, site), n in sites.most_common(60):
