@@ -23,7 +23,7 @@ from ._lib import check, lib, ptr, stream
 
 GEMM, ATTN_FWD, ATTN_BWD, ADLN_FWD, ADLN_BWD = 1, 2, 3, 4, 5
 RELU, NO_BARRIER, CAUSAL = 1, 2, 4
-G_WORKGROUPS = 16
+G_WORKGROUPS = 32          # every CU of one XCD
 
 
 class TokOp(ctypes.Structure):
@@ -70,15 +70,18 @@ def _sync_for(device, xcd):
     key = (str(device), xcd, torch.cuda.current_stream(device).cuda_stream)
     s = _sync.get(key)
     if s is None:
-        s = _sync[key] = (torch.zeros(2, dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int32, device=device))
+        s = _sync[key] = (torch.zeros(32, dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int32, device=device))
     return s
 
 
 def check_status():
     """Raise if any program launch so far gave up on a grid barrier (synchronises; call after warm-up, not per step)."""
     for (dev, xcd, _), (_, status) in _sync.items():
-        if int(status.item()) != 0:
-            raise RuntimeError(f"ast_tok_program: a grid barrier timed out on {dev} (xcd {xcd}); results are invalid")
+        st = int(status.item())
+        if st != 0:
+            status.zero_()
+            why = "a grid barrier timed out" if st == 1 else "the workgroups were not placed on one XCD (blockIdx % 8 != XCC_ID)"
+            raise RuntimeError(f"ast_tok_program: {why} on {dev} (xcd {xcd}, status {st}); results are invalid")
 
 
 def run(oplist, device, xcd, chunk_ends=None):
@@ -103,7 +106,7 @@ def run(oplist, device, xcd, chunk_ends=None):
 
 # ------------------------------------------------------------------------------------------------------------------
 def _pw_ok(pw, rows):
-    return ops._skinny_ok(pw, rows) and pw.Co % 16 == 0 and pw.Ci % 4 == 0 and pw.s_co % 4 == 0
+    return ops._skinny_ok(pw, rows) and pw.Co % 64 == 0 and pw.Ci % 64 == 0 and pw.s_co % 4 == 0
 
 
 def encoder_stack_ok(x, layers):
@@ -111,7 +114,7 @@ def encoder_stack_ok(x, layers):
         return False
     B, L, d = x.shape
     rows = B * L
-    if d != 256 or rows > 64 or L > 16:
+    if d != 256 or rows > 64 or L > 8:
         return False
     for lyr in layers:
         a = lyr.attn
@@ -264,7 +267,7 @@ def decoder_stack_ok(x, memory, layers):
         return False
     B, L, d = x.shape
     Lm = memory.shape[1]
-    if d != 256 or memory.shape[0] != B or memory.shape[2] != d or B * L > 64 or B * Lm > 64 or L > 16 or Lm > 16:
+    if d != 256 or memory.shape[0] != B or memory.shape[2] != d or B * L > 64 or B * Lm > 64 or L > 8 or Lm > 8:
         return False
     for lyr in layers:
         if d // lyr.sa.h > 64 or d // lyr.ca.h > 64:

@@ -8,16 +8,21 @@
 // workgroups walk it together, separated by a grid barrier (0.9 us for G = 16, tools/micro/gridbar.hip) instead of a
 // kernel boundary.
 //
-// Placement: the G workgroups are the ones with blockIdx % 8 == xcd of an 8 G grid -- workgroups are dealt round-robin
-// over the 8 XCDs, so they share one L2 -- and the others exit at once.  This is a speed matter only: every value one
-// op writes and a later op reads goes through agent-scope relaxed atomics (global_load / global_store with sc1:
-// coherent at the device level, no L1 hit, no fence, no cache write-back), which is correct wherever the workgroups
-// land.  (Alternatives measured: __threadfence barriers 3.6-11 us, buffer_inv sc1 4-16 us, both because they write back
-// or invalidate an L2 that concurrent convolution kernels are filling.)  Weights, biases and LayerNorm parameters are
-// read-only during a launch and use plain loads.
+// Placement and coherence: the G workgroups are the first G of a 16 G grid that land on XCD `xcd` (HW_REG_XCC_ID + a
+// ticket), so that they share one L2 and one set of CUs.  Values one op writes and a later op reads are stored and loaded
+// at agent scope (sc1): coherent wherever the workgroups run, at the price of a slow path -- sc1 loads are served from
+// beyond the L2.  What was measured on the way (tools/micro/gridbar.hip, gridbar2.hip, tools/tok_op_cost.py):
+//   * `sc0` loads do NOT bypass the CU's L1 in this mode: correct on large buffers (the L1 thrashes), stale values on
+//     the small ones (<= 8 token rows failed parity);
+//   * buffer_inv sc0 drops nothing, buffer_inv sc1 / __threadfence cost 4-16 us per barrier next to convolution kernels
+//     (they write back / invalidate the whole L2);
+//   * L2-level atomics (no sc1) are not seen by pollers on other CUs; agent-scope ones make a 0.9 (G = 16) - 1.7 us
+//     (G = 32) barrier;
+//   * blockIdx % 8 is the XCD only for a dispatch that starts the round-robin at 0 -- not under graph replay.
+// Weights, biases and LayerNorm parameters are read-only during a launch and use plain loads.
 //
-// Barrier: one monotonically increasing counter per launch (op k waits for G * (k + 1) arrivals); the last workgroup
-// to finish resets it, so replays of the captured graph start from zero again.  A wait that exceeds ~2^21 polls sets
+// Barrier: one monotonically increasing counter per launch (op k waits for G * (k + 1) arrivals), zeroed again by the last
+// workgroup of the grid to exit, so replays of the captured graph start from zero.  A wait that exceeds ~2^21 polls sets
 // *status and the workgroup stops waiting for the rest of the launch (results are then garbage, but the grid drains;
 // the host checks the flag after its warm-up steps).
 #include "ast_common.h"
@@ -28,26 +33,40 @@ namespace {
 constexpr int TOK_MAXOPS = 26;             // 16 + 26 * 152 bytes of kernel arguments (< 4 KB with the three pointers)
 struct TokProgram { int nops, G, xcd, pad; ast_tok_op_t op[TOK_MAXOPS]; };
 
-// ---- device-coherent accesses for values exchanged between workgroups inside a launch --------------------------------
-__device__ __forceinline__ float ldc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ---- agent-scope (sc1) loads for values exchanged between workgroups inside a launch ---------------------------------------
+// The loads are inline asm (16-byte agent-scope loads have no builtin), ISSUED without a wait so that a batch is in
+// flight together; tl_wait() is the s_waitcnt and ties the loaded registers to it ("+v"), so no use can be scheduled
+// ahead of it.  The compiler's own vmcnt counting does not see these loads: it can only over-wait (memory ops return in
+// order), never under-wait.
+__device__ __forceinline__ void tl_issue(f32x4& v, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void tl_issue(float& v, const float* p) { asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory"); }
+template <typename T> __device__ __forceinline__ void tl_wait(T& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) : : "memory"); }
+template <typename T> __device__ __forceinline__ void tl_wait(T& a, T& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
+template <typename T> __device__ __forceinline__ void tl_wait(T& a, T& b, T& c, T& d) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory"); }
+template <typename T, int N> __device__ __forceinline__ void tl_wait_all(T (&v)[N]) {
+  static_assert(N % 4 == 0, "batches of four");
+#pragma unroll
+  for (int k = 0; k < N; k += 4) tl_wait(v[k], v[k + 1], v[k + 2], v[k + 3]);
+}
+__device__ __forceinline__ f32x4 ldc4(const float* p) { f32x4 v; tl_issue(v, p); tl_wait(v); return v; }
+__device__ __forceinline__ float ldc1(const float* p) { float v; tl_issue(v, p); tl_wait(v); return v; }
+// Stores are agent-scope (sc1, acknowledged from beyond the L2): with plain stores s_waitcnt vmcnt(0) returned before
+// the data had reached the L2 and a fast consumer (few token rows) read the old values.
 __device__ __forceinline__ void stc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ f32x2 ldc2(const float* p) {
-  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return __builtin_bit_cast(f32x2, u);
+__device__ __forceinline__ void stc4(float* p, f32x4 v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, f32x2{v.x, v.y}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + 2), __builtin_bit_cast(unsigned long long, f32x2{v.z, v.w}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void stc2(float* p, f32x2 v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ f32x4 ldc4(const float* p) {
-  const f32x2 a = ldc2(p), b = ldc2(p + 2);
-  return f32x4{a.x, a.y, b.x, b.y};
-}
-__device__ __forceinline__ void stc4(float* p, f32x4 v) { stc2(p, f32x2{v.x, v.y}); stc2(p + 2, f32x2{v.z, v.w}); }
 
 struct Bar { unsigned* ctr; int* status; int G; unsigned phase; bool dead; };
 
+// The counter is an agent-scope atomic (performed beyond the L2).  L2-level arrivals (global_atomic_add without sc1,
+// polled with sc0 loads) never became visible to the pollers of other CUs (tools/micro/gridbar2.hip): not an option.
 __device__ __forceinline__ void grid_barrier(Bar& b) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wave's stores have been issued and acknowledged (s_waitcnt)
+  // every store of this wave has been acknowledged by the L2 before the arrival is published (a workgroup-scope fence
+  // alone does not wait for global stores: the waves of a workgroup share their L1)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   ++b.phase;
   if (threadIdx.x == 0 && !b.dead) {
@@ -56,7 +75,7 @@ __device__ __forceinline__ void grid_barrier(Bar& b) {
     int polls = 0;
     while (__hip_atomic_load(b.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       if (++polls > (1 << 21)) { __hip_atomic_store(b.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); b.dead = true; break; }
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
     }
   }
   __syncthreads();
@@ -64,114 +83,159 @@ __device__ __forceinline__ void grid_barrier(Bar& b) {
 }
 
 // ---- GEMM on <= 64 token rows: y[m][n] = epi(sum_k x[m][k] w[n][k]) ------------------------------------------------------
-// v_mfma_f32_16x16x4_f32 (exact f32), the arrangement of skinny_gemm_kernel (skinny.hip): the weight tile is the A
-// operand, lane (i = l & 15, g = l >> 4) loads 16 B of weight row n0 + i and of token row mt * 16 + i at
-// k = kc + 16 s + 4 g, and ends up with n = n0 + 4 g .. + 3 of token row i.  A task is one 16-wide n tile for ALL token
-// rows (MT m tiles share the weight fragment).  Few n tiles (<= G): a workgroup takes the tile and its four waves split K
-// (partials summed through LDS); many: every wave takes its own tile with the whole K.
+// v_mfma_f32_16x16x4_f32 (exact f32).  A task is one 16-wide n tile for ALL token rows (MT m tiles); the four waves of the
+// workgroup split K, their partial tiles are summed through LDS and wave 0 runs the epilogue.
+// Operands go through LDS in 256-float K chunks, loaded as WHOLE ROWS (a wave-instruction = one contiguous KB): the first
+// version loaded MFMA fragments straight from global memory (16 rows x 64 B per instruction, the arrangement of
+// skinny_gemm_kernel), which the texture path serves at 16 B/clk/CU -- with only G CUs at work that was 2.6-3.8 us of an
+// 8.5 us op, the rest being the 4-long dependent MFMA chains (one accumulator per m tile: ~70 cycles per MFMA).  Here the
+// activation chunk is staged once per op (K <= 256) or once per task and chunk, the weight tile per task, fragments come
+// from LDS (ds_read_b128, row pitch 1040 B), and every k sub-step e has its own accumulator (4 MT independent chains).
 // epilogue: + bias, ReLU, dropout draw (the COMBINED ReLU & dropout mask is stored for the backward pass), * mask,
 // + addend (the residual gradient a data gradient is merged with), in the order of skinny_gemm_kernel.
+constexpr int TOK_KC = 256;                      // K chunk (floats)
+constexpr int TOK_PITCH = TOK_KC * 4 + 16;        // LDS row pitch in bytes
+__host__ __device__ constexpr int tok_lds_bytes(int MT) { return (MT * 16 + 16) * TOK_PITCH + 4 * MT * 64 * 16; }
+
 template <int MT>
-__device__ __forceinline__ void tok_gemm(const ast_tok_op_t& op, const int wg, const int G, f32x4 (*part)[4][64], const int64_t* d_offset) {
-  constexpr int CS = MT <= 2 ? 8 : 4;                 // k steps (16 wide) whose loads are in flight together
+__device__ __forceinline__ void tok_gemm(const ast_tok_op_t& op, const int wg, const int G, unsigned char* lds, const int64_t* d_offset) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const int M = op.i[0], N = op.i[1], K = op.i[2], ldx = op.i[3], ldw = op.i[4], ldy = op.i[5];
   const float* x = op.in[0]; const float* w = op.in[1]; const float* bias = op.in[2]; const float* mul_mask = op.in[3];
   const float* addend = op.in[4];
   float* y = op.out[0]; float* drop_mask = op.out[1];
   const bool relu = op.flags & 1;
+  unsigned char* xs = lds;                                   // [MT * 16][TOK_PITCH]
+  unsigned char* ws = lds + MT * 16 * TOK_PITCH;             // [16][TOK_PITCH]
+  f32x4* part = reinterpret_cast<f32x4*>(ws + 16 * TOK_PITCH);      // [4][MT][64]
   const int NT = (N + 15) >> 4;
-  const bool split = NT <= G;
-  const int kq = split ? ((((K + 3) >> 2) + 15) & ~15) : K;        // k per wave
-  const int kbeg = split ? wave * kq : 0, kend = min(K, kbeg + kq);
-  const int unit = split ? wg : wg * 4 + wave, nunits = split ? G : G * 4;
+  const int nkc = (K + TOK_KC - 1) / TOK_KC;
   const uint64_t dbase = drop_mask ? mix64(op.seed ^ mix64((uint64_t)(d_offset ? *d_offset : 0))) : 0;
   const float keep = 1.f / (1.f - op.p);
-  for (int t = unit; t < NT; t += nunits) {
-    const int n0 = t << 4;
-    const bool nv = n0 + i < N;
-    const float* wr = w + (size_t)(nv ? n0 + i : 0) * ldw;
-    f32x4 acc[MT];
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  // Loader: rows r = wave, wave + 4, ...; lane l holds floats 4 l .. 4 l + 3 of the chunk.  The loads of stage n + 1 (next K
+  // chunk, or the next task's weight tile and bias) are ISSUED before the MFMAs of stage n and land in registers while
+  // they run: without that every task was three dependent round trips (activations, weights, bias) around 0.4 us of math.
+  f32x4 xv[MT * 4], wv[4];
+  auto issue_x = [&](int kc0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kc = kbeg; kc < kend; kc += CS * 16) {
-      f32x4 wl[CS], xl[MT][CS];
+    for (int r = 0; r < MT * 4; ++r) {
+      const int m = r * 4 + wave;
+      const bool ok = m < M && kc0 + lane * 4 < K;           // (clamped address + select: the asm load writes every lane)
+      tl_issue(xv[r], x + (ok ? (size_t)m * ldx + kc0 + lane * 4 : 0));
+    }
+  };
+  auto put_x = [&](int kc0) __attribute__((always_inline)) {
 #pragma unroll
-      for (int s = 0; s < CS; ++s) {
-        const int k = kc + s * 16 + 4 * g;
-        const bool kv = k < kend;
-        wl[s] = *reinterpret_cast<const f32x4*>(wr + (kv ? k : 0));
+    for (int r = 0; r < MT * 4; ++r) {
+      const bool ok = r * 4 + wave < M && kc0 + lane * 4 < K;
+      *reinterpret_cast<f32x4*>(xs + (r * 4 + wave) * TOK_PITCH + lane * 16) = ok ? xv[r] : z;
+    }
+  };
+  auto issue_w = [&](int n0, int kc0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int m = mt * 16 + i;
-          xl[mt][s] = ldc4(x + (size_t)(m < M ? m : 0) * ldx + (kv ? k : 0));
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);              // all loads of the chunk in flight before the first MFMA (see skinny.hip)
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + r * 4 + wave;
+      wv[r] = (n < N && kc0 + lane * 4 < K) ? *reinterpret_cast<const f32x4*>(w + (size_t)n * ldw + kc0 + lane * 4) : z;
+    }
+  };
+  auto put_w = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int s = 0; s < CS; ++s) {
-        const bool kv = kc + s * 16 + 4 * g < kend;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 a = (kv && nv) ? wl[s] : z;
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x4*>(ws + (r * 4 + wave) * TOK_PITCH + lane * 16) = wv[r];
+  };
+  auto load_bias = [&](int n0) __attribute__((always_inline)) -> f32x4 {
+    const int nb = n0 + 4 * g;
+    return (bias && nb < N) ? *reinterpret_cast<const f32x4*>(bias + nb) : z;
+  };
+  int t = wg, c = 0;
+  if (t >= NT) return;                                       // (uniform per workgroup)
+  issue_x(0);
+  issue_w(t << 4, 0);
+  f32x4 bnext = load_bias(t << 4), bcur = z;
+  tl_wait_all(xv);
+  bool first = true, have = true;
+  f32x4 acc[MT][4];
+  while (have) {
+    if (nkc > 1 || first) put_x(c * TOK_KC);
+    put_w();
+    if (c == 0) {
+      bcur = bnext;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const f32x4 b = (kv && mt * 16 + i < M) ? xl[mt][s] : z;
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[mt], 0, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e) acc[mt][e] = z;
+    }
+    __syncthreads();
+    int tn = t, cn = c + 1;
+    if (cn == nkc) { cn = 0; tn = t + G; }
+    const bool more = tn < NT;
+    if (more) {
+      if (nkc > 1) issue_x(cn * TOK_KC);
+      issue_w(tn << 4, cn * TOK_KC);
+      if (cn == 0) bnext = load_bias(tn << 4);
+    }
+    const int kw = wave * (TOK_KC / 4);                      // this wave's quarter of the chunk: 4 steps of 16
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int kb = (kw + s4 * 16 + 4 * g) * 4;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ws + i * TOK_PITCH + kb);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(xs + (mt * 16 + i) * TOK_PITCH + kb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[mt][e], 0, 0, 0);
       }
     }
-    if (split) {
+    if (more && nkc > 1) tl_wait_all(xv);                    // landed during the MFMAs; complete before the registers cross the back edge
+    if (c == nkc - 1) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) part[wave][mt][lane] = acc[mt];
-      __syncthreads();
+      for (int mt = 0; mt < MT; ++mt) part[(wave * MT + mt) * 64 + lane] = (acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]);
+      __syncthreads();                                       // partials visible; every fragment read of ws / xs is done
       if (wave == 0) {
+        const int nb = (t << 4) + 4 * g;                     // lane: n = nb .. nb + 3 of token row mt * 16 + i
+        if (nb < N) {                                        // N % 4 == 0 (host)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          f32x4 r = part[0][mt][lane];
+          for (int mt = 0; mt < MT; ++mt) {
+            const int m = mt * 16 + i;
+            if (m >= M) continue;
+            const size_t o = (size_t)m * ldy + nb;
+            f32x4 v = (part[mt * 64 + lane] + part[(MT + mt) * 64 + lane]) + (part[(2 * MT + mt) * 64 + lane] + part[(3 * MT + mt) * 64 + lane]) + bcur;
+            if (relu) {
 #pragma unroll
-          for (int q = 1; q < 4; ++q) { const f32x4 u = part[q][mt][lane]; r += u; }
-          acc[mt] = r;
-        }
-      }
-    }
-    if (!split || wave == 0) {
-      const int nb = n0 + 4 * g;                      // lane: n = nb .. nb + 3 of token row mt * 16 + i
-      if (nb < N) {                                   // N % 4 == 0 (host)
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + nb) : z;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int m = mt * 16 + i;
-          if (m >= M) continue;
-          const size_t o = (size_t)m * ldy + nb;
-          f32x4 v = acc[mt] + b4;
-          if (relu) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-          }
-          if (drop_mask) {
-            f32x4 km;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float kk = dropout_keep(dbase, o + q, op.p, keep);
-              km[q] = (relu && v[q] <= 0.f) ? 0.f : kk;
-              v[q] *= kk;
+              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
             }
-            stc4(drop_mask + o, km);
+            if (drop_mask) {
+              f32x4 km;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float kk = dropout_keep(dbase, o + q, op.p, keep);
+                km[q] = (relu && v[q] <= 0.f) ? 0.f : kk;
+                v[q] *= kk;
+              }
+              stc4(drop_mask + o, km);
+            }
+            if (mul_mask || addend) {
+              f32x4 mm = f32x4{1.f, 1.f, 1.f, 1.f}, ad = z;
+              if (mul_mask) tl_issue(mm, mul_mask + o);
+              if (addend) tl_issue(ad, addend + o);
+              tl_wait(mm, ad);
+              v = v * mm + ad;
+            }
+            stc4(y + o, v);
           }
-          if (mul_mask) v *= ldc4(mul_mask + o);
-          if (addend) v += ldc4(addend + o);
-          stc4(y + o, v);
         }
       }
+    } else {
+      __syncthreads();                                       // the chunk's fragment reads are done before the next one is staged
     }
-    if (split) __syncthreads();                       // `part` is free for the next tile
+    t = tn; c = cn; have = more; first = false;
   }
 }
 
-// ---- attention core for <= 16 tokens: one wave per (batch, head), lane = feature (misc.hip: attn_fwd_kernel / attn_bwd_kernel)
-constexpr int TOK_MAXL = 16;
+// ---- attention core for <= 8 tokens: one wave per (batch, head), lane = feature (misc.hip: attn_fwd_kernel / attn_bwd_kernel)
+constexpr int TOK_MAXL = 8;                      // (a 16-token variant triples the code of this kernel; the model has <= 5 / <= 8)
+// ML = compile-time bound on the token counts (4 or 8): the row loops are fully unrolled over it
+template <int ML>
 __device__ __forceinline__ void tok_attn_fwd(const ast_tok_op_t& op, const int wg, const int G, const int64_t* d_offset) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int B = op.i[0], H = op.i[1], Lq = op.i[2], Lk = op.i[3], dh = op.i[4], ldq = op.i[5], ldk = op.i[6], ldo = op.i[7];
@@ -182,20 +246,31 @@ __device__ __forceinline__ void tok_attn_fwd(const ast_tok_op_t& op, const int w
   const uint64_t dbase = pdrop > 0.f ? mix64(op.seed ^ mix64((uint64_t)(d_offset ? *d_offset : 0))) : 0;
   const float dkeep = 1.f / (1.f - pdrop);
   const float scale = rsqrtf((float)dh);
+  const int ln = lane < dh ? lane : 0;
   for (int t = wg * 4 + wave; t < B * H; t += G * 4) {
     const int b = t / H, h = t % H;
-    float kv[TOK_MAXL], vv[TOK_MAXL];
+    float kv[ML], vv[ML], qv[ML];
 #pragma unroll
-    for (int j = 0; j < TOK_MAXL; ++j) {
-      kv[j] = (j < Lk && lane < dh) ? ldc1(k + ((size_t)b * Lk + j) * ldk + h * dh + lane) : 0.f;
-      vv[j] = (j < Lk && lane < dh) ? ldc1(v + ((size_t)b * Lk + j) * ldk + h * dh + lane) : 0.f;
+    for (int j = 0; j < ML; ++j) {            // every row of K, V and Q in flight together (clamped addresses, masked below)
+      const int jk = j < Lk ? j : 0, jq = j < Lq ? j : 0;
+      tl_issue(kv[j], k + ((size_t)b * Lk + jk) * ldk + h * dh + ln);
+      tl_issue(vv[j], v + ((size_t)b * Lk + jk) * ldk + h * dh + ln);
+      tl_issue(qv[j], q + ((size_t)b * Lq + jq) * ldq + h * dh + ln);
     }
-    for (int iq = 0; iq < Lq; ++iq) {
-      const float qi = lane < dh ? ldc1(q + ((size_t)b * Lq + iq) * ldq + h * dh + lane) * scale : 0.f;
-      float s[TOK_MAXL];
+    tl_wait_all(kv); tl_wait_all(vv); tl_wait_all(qv);
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {
+      kv[j] = (j < Lk && lane < dh) ? kv[j] : 0.f;
+      vv[j] = (j < Lk && lane < dh) ? vv[j] : 0.f;
+    }
+#pragma unroll
+    for (int iq = 0; iq < ML; ++iq) {
+      if (iq >= Lq) break;
+      const float qi = lane < dh ? qv[iq] * scale : 0.f;
+      float s[ML];
       float mx = -INFINITY;
 #pragma unroll
-      for (int j = 0; j < TOK_MAXL; ++j) {
+      for (int j = 0; j < ML; ++j) {
         s[j] = -INFINITY;
         if (j < Lk) {
           s[j] = wave_sum(qi * kv[j]);
@@ -205,11 +280,11 @@ __device__ __forceinline__ void tok_attn_fwd(const ast_tok_op_t& op, const int w
       }
       float den = 0.f;
 #pragma unroll
-      for (int j = 0; j < TOK_MAXL; ++j) { s[j] = j < Lk ? __expf(s[j] - mx) : 0.f; den += s[j]; }
+      for (int j = 0; j < ML; ++j) { s[j] = j < Lk ? __expf(s[j] - mx) : 0.f; den += s[j]; }
       float acc = 0.f;
       const size_t pbase = (((size_t)b * H + h) * Lq + iq) * Lk;
 #pragma unroll
-      for (int j = 0; j < TOK_MAXL; ++j) {
+      for (int j = 0; j < ML; ++j) {
         if (j < Lk) {
           const float p = s[j] / den;
           if (lane == 0) stc1(probs + pbase + j, p);
@@ -221,6 +296,7 @@ __device__ __forceinline__ void tok_attn_fwd(const ast_tok_op_t& op, const int w
   }
 }
 
+template <int ML>
 __device__ __forceinline__ void tok_attn_bwd(const ast_tok_op_t& op, const int wg, const int G, const int64_t* d_offset) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int B = op.i[0], H = op.i[1], Lq = op.i[2], Lk = op.i[3], dh = op.i[4], ldq = op.i[5], ldk = op.i[6], ldo = op.i[7];
@@ -231,35 +307,51 @@ __device__ __forceinline__ void tok_attn_bwd(const ast_tok_op_t& op, const int w
   const uint64_t dbase = pdrop > 0.f ? mix64(op.seed ^ mix64((uint64_t)(d_offset ? *d_offset : 0))) : 0;
   const float dkeep = 1.f / (1.f - pdrop);
   const float scale = rsqrtf((float)dh);
+  const int ln = lane < dh ? lane : 0;
   for (int t = wg * 4 + wave; t < B * H; t += G * 4) {
     const int b = t / H, h = t % H;
-    float kv[TOK_MAXL], vv[TOK_MAXL], dkv[TOK_MAXL], dvv[TOK_MAXL];
+    float kv[ML], vv[ML], qv[ML], dov[ML], dkv[ML], dvv[ML];
 #pragma unroll
-    for (int j = 0; j < TOK_MAXL; ++j) {
-      kv[j] = (j < Lk && lane < dh) ? ldc1(k + ((size_t)b * Lk + j) * ldk + h * dh + lane) : 0.f;
-      vv[j] = (j < Lk && lane < dh) ? ldc1(v + ((size_t)b * Lk + j) * ldk + h * dh + lane) : 0.f;
+    for (int j = 0; j < ML; ++j) {
+      const int jk = j < Lk ? j : 0, jq = j < Lq ? j : 0;
+      tl_issue(kv[j], k + ((size_t)b * Lk + jk) * ldk + h * dh + ln);
+      tl_issue(vv[j], v + ((size_t)b * Lk + jk) * ldk + h * dh + ln);
+      tl_issue(qv[j], q + ((size_t)b * Lq + jq) * ldq + h * dh + ln);
+      tl_issue(dov[j], dout + ((size_t)b * Lq + jq) * ldo + h * dh + ln);
+    }
+    tl_wait_all(kv); tl_wait_all(vv); tl_wait_all(qv); tl_wait_all(dov);
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {
+      kv[j] = (j < Lk && lane < dh) ? kv[j] : 0.f;
+      vv[j] = (j < Lk && lane < dh) ? vv[j] : 0.f;
       dkv[j] = 0.f; dvv[j] = 0.f;
     }
-    for (int iq = 0; iq < Lq; ++iq) {
-      const float qi = lane < dh ? ldc1(q + ((size_t)b * Lq + iq) * ldq + h * dh + lane) : 0.f;
-      const float doi = lane < dh ? ldc1(dout + ((size_t)b * Lq + iq) * ldo + h * dh + lane) : 0.f;
+#pragma unroll
+    for (int iq = 0; iq < ML; ++iq) {
+      if (iq >= Lq) break;
+      const float qi = lane < dh ? qv[iq] : 0.f;
+      const float doi = lane < dh ? dov[iq] : 0.f;
       const size_t pbase = (((size_t)b * H + h) * Lq + iq) * Lk;
-      float dp[TOK_MAXL], p[TOK_MAXL];
+      float dp[ML], p[ML];
+#pragma unroll
+      for (int j = 0; j < ML; ++j) tl_issue(p[j], probs + pbase + (j < Lk ? j : 0));
+      tl_wait_all(p);
       float dot = 0.f;
 #pragma unroll
-      for (int j = 0; j < TOK_MAXL; ++j) {
-        p[j] = 0.f; dp[j] = 0.f;
+      for (int j = 0; j < ML; ++j) {
+        dp[j] = 0.f;
         if (j < Lk) {
-          p[j] = ldc1(probs + pbase + j);
           const float m = pdrop > 0.f ? dropout_keep(dbase, pbase + j, pdrop, dkeep) : 1.f;
           dvv[j] += p[j] * m * doi;
           dp[j] = wave_sum(doi * vv[j]) * m;
           dot += dp[j] * p[j];
+        } else {
+          p[j] = 0.f;
         }
       }
       float dqi = 0.f;
 #pragma unroll
-      for (int j = 0; j < TOK_MAXL; ++j) {
+      for (int j = 0; j < ML; ++j) {
         if (j < Lk) {
           const float ds = p[j] * (dp[j] - dot) * scale;
           dqi += ds * kv[j];
@@ -270,7 +362,7 @@ __device__ __forceinline__ void tok_attn_bwd(const ast_tok_op_t& op, const int w
     }
     if (lane < dh) {
 #pragma unroll
-      for (int j = 0; j < TOK_MAXL; ++j)
+      for (int j = 0; j < ML; ++j)
         if (j < Lk) {
           stc1(dk + ((size_t)b * Lk + j) * ldk + h * dh + lane, dkv[j]);
           stc1(dv + ((size_t)b * Lk + j) * ldk + h * dh + lane, dvv[j]);
@@ -295,8 +387,10 @@ __device__ __forceinline__ void tok_adln_fwd(const ast_tok_op_t& op, const int w
   const f32x4 b4 = gamma ? *reinterpret_cast<const f32x4*>(beta + lane * 4) : z;
   for (int row = wg * 4 + wave; row < rows; row += G * 4) {
     const size_t o = (size_t)row * D + lane * 4;
-    f32x4 sv = ldc4(sub + o);
-    const f32x4 xv = x ? ldc4(x + o) : z;
+    f32x4 sv, xv = z;
+    tl_issue(sv, sub + o);
+    if (x) tl_issue(xv, x + o);
+    tl_wait(sv, xv);
     if (p > 0.f) {
       f32x4 m4;
 #pragma unroll
@@ -332,11 +426,12 @@ __device__ __forceinline__ void tok_adln_bwd(const ast_tok_op_t& op, const int w
   f32x4 accg = z, accb = z;                           // this wave's rows: one atomic per element at the end
   for (int row = wg * 4 + wave; row < rows; row += G * 4) {
     const size_t o = (size_t)row * D + lane * 4;
-    const f32x4 dy4 = dy ? ldc4(dy + o) : z;
-    const f32x4 s4 = dy ? ldc4(s + o) : z;
-    const f32x4 e4 = ds_ext ? ldc4(ds_ext + o) : z;
-    const f32x4 k4 = mask ? ldc4(mask + o) : f32x4{1.f, 1.f, 1.f, 1.f};
-    const float m = dy ? ldc1(mean + row) : 0.f, r = dy ? ldc1(rstd + row) : 0.f;
+    f32x4 dy4 = z, s4 = z, e4 = z, k4 = f32x4{1.f, 1.f, 1.f, 1.f};
+    float m = 0.f, r = 0.f;
+    if (dy) { tl_issue(dy4, dy + o); tl_issue(s4, s + o); tl_issue(m, mean + row); tl_issue(r, rstd + row); }
+    if (ds_ext) tl_issue(e4, ds_ext + o);
+    if (mask) tl_issue(k4, mask + o);
+    tl_wait(dy4, s4, e4, k4); tl_wait(m, r);
     f32x4 d4 = e4, xh4 = z;
     if (dy) {
       float a = 0.f, b = 0.f;
@@ -356,44 +451,82 @@ __device__ __forceinline__ void tok_adln_bwd(const ast_tok_op_t& op, const int w
   }
 }
 
+#ifdef AST_STAMPS
+__device__ unsigned long long tok_stamps[32 * 64 * 3];      // [workgroup][op][start, computed, barrier passed] wall clock (100 MHz)
+#define TOK_STAMP(j) do { if (threadIdx.x == 0 && wg < 32 && k < 64) tok_stamps[(wg * 64 + k) * 3 + (j)] = (j) == 2 ? __builtin_readcyclecounter() : wall_clock64(); } while (0)
+#else
+#define TOK_STAMP(j) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void tok_program_kernel(const TokProgram prog, unsigned* __restrict__ sync, int* __restrict__ status,
                                                           const int64_t* __restrict__ d_offset) {
-  if ((int)(blockIdx.x & 7) != prog.xcd) return;
-  __shared__ f32x4 part[4][4][64];
-  const int wg = blockIdx.x >> 3, G = prog.G;
+  // Participants = the first G workgroups that LAND on XCD prog.xcd (HW_REG_XCC_ID) and draw a ticket.  Workgroups are
+  // dealt over the 8 XCDs roughly round-robin, but neither the starting XCD nor the exact share is fixed (blockIdx % 8
+  // was wrong under graph replay, and an 8 G grid did not always put G on the target), so the grid is 16 G and the surplus
+  // exits.  `sync` (agent-scope atomics throughout): [0] barrier arrivals, [1] finished participants, and in another cache
+  // line [16] exited workgroups, [17] tickets.
+  // The last participant zeroes the first group, the last workgroup of the grid the second: the next launch (a replay of
+  // the same graph node) starts from zero.
+  extern __shared__ __attribute__((aligned(16))) unsigned char tok_lds[];
+  const int G = prog.G;
+  auto leave = [&]() __attribute__((always_inline)) {
+    if (threadIdx.x == 0) {
+      const unsigned gone = __hip_atomic_fetch_add(sync + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (gone == gridDim.x - 1) {
+        __hip_atomic_store(sync + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync + 17, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  if ((int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) != prog.xcd) { leave(); return; }
+  if (threadIdx.x == 0) *reinterpret_cast<unsigned*>(tok_lds) = __hip_atomic_fetch_add(sync + 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int wg = (int)*reinterpret_cast<volatile unsigned*>(tok_lds);
+  __syncthreads();
+  if (wg >= G) { leave(); return; }
   Bar bar{sync, status, G, 0u, false};
   for (int k = 0; k < prog.nops; ++k) {
     const ast_tok_op_t& op = prog.op[k];
+    TOK_STAMP(0);
     switch (op.type) {
       case AST_TOK_GEMM: {
         const int M = op.i[0];
-        if (M <= 16) tok_gemm<1>(op, wg, G, part, d_offset);
-        else if (M <= 32) tok_gemm<2>(op, wg, G, part, d_offset);
-        else tok_gemm<4>(op, wg, G, part, d_offset);
+        if (M <= 16) tok_gemm<1>(op, wg, G, tok_lds, d_offset);
+        else if (M <= 32) tok_gemm<2>(op, wg, G, tok_lds, d_offset);
+        else tok_gemm<4>(op, wg, G, tok_lds, d_offset);
       } break;
-      case AST_TOK_ATTN_FWD: tok_attn_fwd(op, wg, G, d_offset); break;
-      case AST_TOK_ATTN_BWD: tok_attn_bwd(op, wg, G, d_offset); break;
+      case AST_TOK_ATTN_FWD: {
+        const int ml = max(op.i[2], op.i[3]);
+        if (ml <= 4) tok_attn_fwd<4>(op, wg, G, d_offset); else tok_attn_fwd<8>(op, wg, G, d_offset);
+      } break;
+      case AST_TOK_ATTN_BWD: {
+        const int ml = max(op.i[2], op.i[3]);
+        if (ml <= 4) tok_attn_bwd<4>(op, wg, G, d_offset); else tok_attn_bwd<8>(op, wg, G, d_offset);
+      } break;
       case AST_TOK_ADLN_FWD: tok_adln_fwd(op, wg, G, d_offset); break;
       case AST_TOK_ADLN_BWD: tok_adln_bwd(op, wg, G); break;
       default: break;
     }
+    TOK_STAMP(1);
     if (!(op.flags & AST_TOK_NO_BARRIER) && k + 1 < prog.nops) grid_barrier(bar);
+    TOK_STAMP(2);
   }
-  // leave the counters at zero for the next launch (a replay of the same graph node): the last workgroup to get here
-  // knows that every other one has left its last barrier
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned done = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (done == (unsigned)G - 1) {
-      __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  if (threadIdx.x == 0 && __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)G - 1) {
+    __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // every participant has left its last barrier
+    __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  leave();
 }
 
 }  // namespace
 
 extern "C" int ast_tok_max_ops(void) { return TOK_MAXOPS; }
+#ifdef AST_STAMPS
+extern "C" int ast_debug_read_tok_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tok_stamps), sizeof(unsigned long long) * 32 * 64 * 3);
+}
+#endif
 
 extern "C" int ast_tok_program(const ast_tok_op_t* ops, int nops, int G, int xcd, void* sync, int* status, const int64_t* d_offset,
                                void* stream) {
@@ -405,8 +538,8 @@ extern "C" int ast_tok_program(const ast_tok_op_t* ops, int nops, int G, int xcd
     const ast_tok_op_t& op = ops[k];
     switch (op.type) {
       case AST_TOK_GEMM:
-        if (op.i[0] <= 0 || op.i[0] > 64 || op.i[1] % 16 || op.i[2] % 4 || op.i[3] % 4 || op.i[4] % 4 || op.i[5] % 4 || !op.in[0] || !op.in[1] || !op.out[0])
-          AST_FAIL("ast_tok_program: op %d: GEMM needs 1..64 rows, N %% 16 == 0, K and the leading dimensions %% 4 == 0 (M %d N %d K %d)", k, op.i[0], op.i[1], op.i[2]);
+        if (op.i[0] <= 0 || op.i[0] > 64 || op.i[1] % 16 || op.i[2] % 64 || op.i[3] % 4 || op.i[4] % 4 || op.i[5] % 4 || !op.in[0] || !op.in[1] || !op.out[0])
+          AST_FAIL("ast_tok_program: op %d: GEMM needs 1..64 rows, N %% 16 == 0, K %% 64 == 0, leading dimensions %% 4 == 0 (M %d N %d K %d)", k, op.i[0], op.i[1], op.i[2]);
         if (op.out[1] && !(op.p >= 0.f && op.p < 1.f)) AST_FAIL("ast_tok_program: op %d: mask output needs 0 <= p < 1", k);
         break;
       case AST_TOK_ATTN_FWD: case AST_TOK_ATTN_BWD:
@@ -420,7 +553,16 @@ extern "C" int ast_tok_program(const ast_tok_op_t* ops, int nops, int G, int xcd
     }
     prog.op[k] = op;
   }
-  hipLaunchKernelGGL(tok_program_kernel, dim3(8 * G), dim3(256), 0, (hipStream_t)stream, prog, (unsigned*)sync, status, d_offset);
+  int mt = 1;
+  for (int k = 0; k < nops; ++k)
+    if (ops[k].type == AST_TOK_GEMM) mt = std::max(mt, ops[k].i[0] <= 16 ? 1 : (ops[k].i[0] <= 32 ? 2 : 4));
+  const int lds = tok_lds_bytes(mt);
+  static bool attr_set = false;
+  if (!attr_set) {
+    AST_HIP(hipFuncSetAttribute((const void*)tok_program_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tok_lds_bytes(4)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(tok_program_kernel, dim3(16 * G), dim3(256), lds, (hipStream_t)stream, prog, (unsigned*)sync, status, d_offset);
   AST_CHECK_LAUNCH();
   return 0;
 }

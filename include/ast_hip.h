@@ -345,8 +345,8 @@ int ast_resample_poly(const float* x, int B, int n, const float* kern, int orig,
  * f32 row-major; an op reads what earlier ops of the same launch wrote.  ast_tok_max_ops() ops per launch at most.
  *   AST_TOK_GEMM      y[M][N] = epi(x[M][K] w[N][K]^T): i = {M, N, K, ldx, ldw, ldy}; in = {x, w, bias?, mul_mask?, addend?};
  *                     out = {y, drop_mask?}; flags & 1: ReLU.  epi: +bias, ReLU, dropout (p, seed; the combined ReLU &
- *                     dropout mask goes to drop_mask), * mul_mask, + addend.  M <= 64, N % 16 == 0.
- *   AST_TOK_ATTN_FWD  softmax(q k^T / sqrt(dh)) v per (batch, head): i = {B, H, Lq, Lk, dh, ldq, ldk, ldo}; in = {q, k, v};
+ *                     dropout mask goes to drop_mask), * mul_mask, + addend.  M <= 64, N % 16 == 0, K % 64 == 0.
+ *   AST_TOK_ATTN_FWD  softmax(q k^T / sqrt(dh)) v per (batch, head), Lq, Lk <= 8: i = {B, H, Lq, Lk, dh, ldq, ldk, ldo}; in = {q, k, v};
  *                     out = {o, probs (B,H,Lq,Lk)}; flags & 4: causal; p, seed: dropout on the probabilities (redrawn by _BWD).
  *   AST_TOK_ATTN_BWD  same i; in = {dout, q, k, v, probs}; out = {dq, dk, dv}.
  *   AST_TOK_ADLN_FWD  s = x + dropout(sub), y = LayerNorm(s): i = {rows, 256}; in = {x?, sub, gamma?, beta?};
@@ -354,7 +354,7 @@ int ast_resample_poly(const float* x, int B, int n, const float* kern, int orig,
  *   AST_TOK_ADLN_BWD  ds = ds_ext + LayerNorm_bwd(dy; s), dx = ds, dsub = ds * mask: i = {rows, 256};
  *                     in = {dy?, ds_ext?, s, gamma, mean, rstd, mask?}; out = {dx?, dsub?, dgamma?, dbeta?} (+= for the last two).
  * flags & AST_TOK_NO_BARRIER: the next op does not depend on this one (no grid barrier between them).
- * G (<= 32) workgroups do the work (those with blockIdx % 8 == xcd of an 8 G grid); sync = 2 zeroed uint32 owned by this
+ * G (<= 32) workgroups do the work (those of an 8 G grid that land on XCD xcd); sync = 32 zeroed uint32 (128-byte aligned) owned by this
  * call chain (launches that may run concurrently need their own); *status becomes 1 if a barrier wait timed out;
  * d_offset = the device step counter of the dropout draws (as ast_dropout_fwd). */
 enum { AST_TOK_GEMM = 1, AST_TOK_ATTN_FWD = 2, AST_TOK_ATTN_BWD = 3, AST_TOK_ADLN_FWD = 4, AST_TOK_ADLN_BWD = 5 };

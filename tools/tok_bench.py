@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Transformer stacks alone (forward + backward, graph replay): token programs vs the per-operator path.
+tools/tok_bench.py [B=8] [S=2]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "audio-style-transfer_amd")); sys.path.insert(0, ROOT)
+import torch
+import ast_amd
+from ast_amd import config, tokprog
+from ast_amd.style_encoder import _module_bank
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+dev = "cuda"
+config.set_compute_dtype(torch.bfloat16)
+
+def bench(name, build):
+    for mode in (False, True):
+        config.tok_programs = mode
+        fn = build()
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn()
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(g):
+            fn()
+        for _ in range(3): g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): g.replay()
+        e1.record(); torch.cuda.synchronize()
+        print(f"{name:28s} {'token programs' if mode else 'per operator  '}: {e0.elapsed_time(e1) * 1000 / 20:8.1f} us per forward+backward", flush=True)
+    tokprog.check_status()
+
+def enc(ctor, L):
+    def build():
+        m = ctor().to(dev).train()
+        seq = torch.randn(B, L, 256, device=dev, requires_grad=True)
+        def fn():
+            _module_bank(m).prepare(True)
+            if config.tok_programs:
+                out = tokprog.encoder_stack(seq, m._layers, True, 0)
+            else:
+                out = seq
+                for lyr in m._layers: out = lyr(out, True)
+            out.sum().backward()
+        return fn
+    return build
+
+def dec():
+    m = ast_amd.Decoder().to(dev).train()
+    tgt = torch.randn(B, S, 256, device=dev, requires_grad=True)
+    mem = torch.randn(B, 2 * S, 256, device=dev, requires_grad=True)
+    def fn():
+        m._prepare()
+        m._stack(tgt, mem).sum().backward()
+    return fn
+
+bench(f"style stack (rows {B * (S + 1)})", enc(ast_amd.StyleEncoder, S + 1))
+bench(f"content stack (rows {B * S})", enc(ast_amd.ContentEncoder, S))
+bench(f"decoder stack (rows {B * S})", dec)
