@@ -131,8 +131,8 @@ def test_stack_programs_with_dropout_are_consistent():
     old = config.tok_programs
     config.tok_programs = True
     try:
-        assert tokprog.decoder_stack_ok(tgt0, mem0, m._layers)
         _, grad = loss_at(tgt0, True)
+        assert tokprog.decoder_stack_ok(tgt0, mem0, m._layers)
         eps = 1e-2
         with torch.no_grad():
             lp, _ = loss_at(tgt0 + eps * d_t, False)
