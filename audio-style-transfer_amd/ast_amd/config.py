@@ -18,11 +18,12 @@ def set_compute_dtype(dtype):
 # the reference the fused kernels are tested against; AST_FUSED_TOKENS=0 selects it for A/B timing.
 import os as _os
 fused_tokens = _os.environ.get("AST_FUSED_TOKENS", "1") != "0"
-# transformer stacks as token programs (ast_tok_program: a few launches per stack instead of one per operator).
-# EXPERIMENTAL, off by default: parity-green but measured SLOWER than the per-operator path (style stack forward + backward
-# 495 vs 350 us, the whole step 6.87 vs 6.60 ms): the coherent (sc1) data path between the ops of a launch
-# and the <= 32 CUs of one XCD cost more than the ~1.7 us per dependent graph node they save.
-tok_programs = _os.environ.get("AST_TOK_PROGRAMS", "0") != "0"
+# Transformer stacks as token op lists (ast_amd/tokprog.py, ast_tok_program): 0 = off (one autograd node per operator),
+# 1 = one autograd node per STACK, its ops launched one kernel each (the engine's gradient sums, the separate ReLU-backward and
+# LayerNorm launches disappear into fused epilogues), 2 = the same op lists walked by ONE persistent launch per few layers
+# with grid barriers.  Both are parity-green (tests/test_gpu_tokprog.py) and neither is faster on MI355X (stacks
+# forward + backward 347 / 401 / 509 us, the whole step unchanged), so the default stays 0.
+tok_programs = int(_os.environ.get("AST_TOK_PROGRAMS", "0"))
 
 # BatchNorm batch statistics accumulated in the producing conv GEMM's epilogue instead of a separate pass over its
 # output (AST_FUSED_BN_STATS=0 keeps the separate pass: the reference path for tests and A/B timing).

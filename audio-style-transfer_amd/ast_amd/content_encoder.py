@@ -42,7 +42,7 @@ class ContentEncoder(nn.Module):
         if self._inp is not None:
             feat = L.linear(feat, self._inp)
         seq = L.layer_norm(self.pos_encoder(feat.view(B, S, -1)), self.norm)
-        if config.tok_programs and tokprog.encoder_stack_ok(seq, self._layers):
+        if config.tok_programs > 0 and tokprog.encoder_stack_ok(seq, self._layers):
             seq = tokprog.encoder_stack(seq, self._layers, self.training, xcd=1)
         else:
             for lyr in self._layers:

@@ -127,7 +127,7 @@ class Decoder(nn.Module):
         return self._memory(content_emb, class_emb)
 
     def _stack(self, tgt, memory):
-        if config.tok_programs and tokprog.decoder_stack_ok(tgt, memory, self._layers):
+        if config.tok_programs > 0 and tokprog.decoder_stack_ok(tgt, memory, self._layers):
             return tokprog.decoder_stack(tgt, memory, self._layers, self.training)
         for lyr in self._layers:
             tgt = lyr(tgt, memory, self.training)

@@ -157,7 +157,7 @@ class StyleEncoder(nn.Module):
         if self.use_cls:
             seq = torch.cat([self.cls_token.expand(B, -1, -1), seq], dim=1)
         seq = L.layer_norm(self.pos_encoder(seq), self.norm)
-        if config.tok_programs and tokprog.encoder_stack_ok(seq, self._layers):
+        if config.tok_programs > 0 and tokprog.encoder_stack_ok(seq, self._layers):
             seq = tokprog.encoder_stack(seq, self._layers, self.training, xcd=0)
         else:
             for lyr in self._layers:

@@ -84,14 +84,25 @@ def check_status():
             raise RuntimeError(f"ast_tok_program: {why} on {dev} (xcd {xcd}, status {st}); results are invalid")
 
 
-def run(oplist, device, xcd, chunk_ends=None):
-    """Launch the ops in chunks of at most ast_tok_max_ops(); `chunk_ends` = indices after which a launch may end."""
+def run(oplist, device, xcd, chunk_ends=None, persistent=None):
+    """Execute the ops: one kernel per op (config.tok_programs == 1), or persistent launches of at most ast_tok_max_ops()
+    ops (== 2; `chunk_ends` = indices after which a launch may end)."""
     if not oplist:
         return
-    sync, status = _sync_for(device, xcd)
+    from . import config
+    if persistent is None:
+        persistent = config.tok_programs == 2
     ctr = ops._DropState.counter
     if ctr is None or ctr.device != device:
         ctr = ops._DropState.counter = torch.zeros(1, dtype=torch.int64, device=device)
+    if not persistent:
+        cap = lib().ast_tok_max_ops()
+        for start in range(0, len(oplist), cap):
+            part = oplist[start:start + cap]
+            arr = (TokOp * len(part))(*part)
+            check(lib().ast_tok_program(arr, len(part), 0, 0, None, None, ptr(ctr), stream()), "ast_tok_program")
+        return
+    sync, status = _sync_for(device, xcd)
     cap = lib().ast_tok_max_ops()
     ends = sorted(set(chunk_ends or range(1, len(oplist) + 1)) | {len(oplist)})
     start = 0

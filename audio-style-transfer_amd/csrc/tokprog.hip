@@ -35,28 +35,44 @@ struct TokProgram { int nops, G, xcd, pad; ast_tok_op_t op[TOK_MAXOPS]; };
 
 // ---- agent-scope (sc1) loads for values exchanged between workgroups inside a launch ---------------------------------------
 // The loads are inline asm (16-byte agent-scope loads have no builtin), ISSUED without a wait so that a batch is in
-// flight together; tl_wait() is the s_waitcnt and ties the loaded registers to it ("+v"), so no use can be scheduled
+// flight together; TL<COH>::wait() is the s_waitcnt and ties the loaded registers to it ("+v"), so no use can be scheduled
 // ahead of it.  The compiler's own vmcnt counting does not see these loads: it can only over-wait (memory ops return in
 // order), never under-wait.
-__device__ __forceinline__ void tl_issue(f32x4& v, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory"); }
-__device__ __forceinline__ void tl_issue(float& v, const float* p) { asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory"); }
-template <typename T> __device__ __forceinline__ void tl_wait(T& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) : : "memory"); }
-template <typename T> __device__ __forceinline__ void tl_wait(T& a, T& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
-template <typename T> __device__ __forceinline__ void tl_wait(T& a, T& b, T& c, T& d) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory"); }
-template <typename T, int N> __device__ __forceinline__ void tl_wait_all(T (&v)[N]) {
-  static_assert(N % 4 == 0, "batches of four");
+// COH = true: inside a persistent program (agent-scope, see above).  COH = false: one launch per op -- the kernel boundary
+// orders everything and these are plain loads and stores.
+template <bool COH> struct TL {
+  static __device__ __forceinline__ void issue(f32x4& v, const float* p) {
+    if constexpr (COH) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
+    else v = *reinterpret_cast<const f32x4*>(p);
+  }
+  static __device__ __forceinline__ void issue(float& v, const float* p) {
+    if constexpr (COH) asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
+    else v = *p;
+  }
+  template <typename T> static __device__ __forceinline__ void wait(T& a) { if constexpr (COH) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a) : : "memory"); }
+  template <typename T> static __device__ __forceinline__ void wait(T& a, T& b) { if constexpr (COH) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
+  template <typename T> static __device__ __forceinline__ void wait(T& a, T& b, T& c, T& d) {
+    if constexpr (COH) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+  }
+  template <typename T, int N> static __device__ __forceinline__ void wait_all(T (&v)[N]) {
+    static_assert(N % 4 == 0, "batches of four");
 #pragma unroll
-  for (int k = 0; k < N; k += 4) tl_wait(v[k], v[k + 1], v[k + 2], v[k + 3]);
-}
-__device__ __forceinline__ f32x4 ldc4(const float* p) { f32x4 v; tl_issue(v, p); tl_wait(v); return v; }
-__device__ __forceinline__ float ldc1(const float* p) { float v; tl_issue(v, p); tl_wait(v); return v; }
-// Stores are agent-scope (sc1, acknowledged from beyond the L2): with plain stores s_waitcnt vmcnt(0) returned before
-// the data had reached the L2 and a fast consumer (few token rows) read the old values.
-__device__ __forceinline__ void stc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void stc4(float* p, f32x4 v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, f32x2{v.x, v.y}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + 2), __builtin_bit_cast(unsigned long long, f32x2{v.z, v.w}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+    for (int k = 0; k < N; k += 4) wait(v[k], v[k + 1], v[k + 2], v[k + 3]);
+  }
+  // Stores are agent-scope (sc1, acknowledged from beyond the L2): with plain stores s_waitcnt vmcnt(0) returned before
+  // the data was visible to the other workgroups' sc1 loads.
+  static __device__ __forceinline__ void st1(float* p, float v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+  }
+  static __device__ __forceinline__ void st4(float* p, f32x4 v) {
+    if constexpr (COH) {
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, f32x2{v.x, v.y}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(p + 2), __builtin_bit_cast(unsigned long long, f32x2{v.z, v.w}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      *reinterpret_cast<f32x4*>(p) = v;
+    }
+  }
+};
 
 struct Bar { unsigned* ctr; int* status; int G; unsigned phase; bool dead; };
 
@@ -97,7 +113,7 @@ constexpr int TOK_KC = 256;                      // K chunk (floats)
 constexpr int TOK_PITCH = TOK_KC * 4 + 16;        // LDS row pitch in bytes
 __host__ __device__ constexpr int tok_lds_bytes(int MT) { return (MT * 16 + 16) * TOK_PITCH + 4 * MT * 64 * 16; }
 
-template <int MT>
+template <bool COH, int MT>
 __device__ __forceinline__ void tok_gemm(const ast_tok_op_t& op, const int wg, const int G, unsigned char* lds, const int64_t* d_offset) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const int M = op.i[0], N = op.i[1], K = op.i[2], ldx = op.i[3], ldw = op.i[4], ldy = op.i[5];
@@ -122,7 +138,7 @@ __device__ __forceinline__ void tok_gemm(const ast_tok_op_t& op, const int wg, c
     for (int r = 0; r < MT * 4; ++r) {
       const int m = r * 4 + wave;
       const bool ok = m < M && kc0 + lane * 4 < K;           // (clamped address + select: the asm load writes every lane)
-      tl_issue(xv[r], x + (ok ? (size_t)m * ldx + kc0 + lane * 4 : 0));
+      TL<COH>::issue(xv[r], x + (ok ? (size_t)m * ldx + kc0 + lane * 4 : 0));
     }
   };
   auto put_x = [&](int kc0) __attribute__((always_inline)) {
@@ -152,7 +168,7 @@ __device__ __forceinline__ void tok_gemm(const ast_tok_op_t& op, const int wg, c
   issue_x(0);
   issue_w(t << 4, 0);
   f32x4 bnext = load_bias(t << 4), bcur = z;
-  tl_wait_all(xv);
+  TL<COH>::wait_all(xv);
   bool first = true, have = true;
   f32x4 acc[MT][4];
   while (have) {
@@ -186,7 +202,7 @@ __device__ __forceinline__ void tok_gemm(const ast_tok_op_t& op, const int wg, c
         for (int e = 0; e < 4; ++e) acc[mt][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc[mt][e], 0, 0, 0);
       }
     }
-    if (more && nkc > 1) tl_wait_all(xv);                    // landed during the MFMAs; complete before the registers cross the back edge
+    if (more && nkc > 1) TL<COH>::wait_all(xv);                    // landed during the MFMAs; complete before the registers cross the back edge
     if (c == nkc - 1) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) part[(wave * MT + mt) * 64 + lane] = (acc[mt][0] + acc[mt][1]) + (acc[mt][2] + acc[mt][3]);
@@ -212,16 +228,16 @@ __device__ __forceinline__ void tok_gemm(const ast_tok_op_t& op, const int wg, c
                 km[q] = (relu && v[q] <= 0.f) ? 0.f : kk;
                 v[q] *= kk;
               }
-              stc4(drop_mask + o, km);
+              TL<COH>::st4(drop_mask + o, km);
             }
             if (mul_mask || addend) {
               f32x4 mm = f32x4{1.f, 1.f, 1.f, 1.f}, ad = z;
-              if (mul_mask) tl_issue(mm, mul_mask + o);
-              if (addend) tl_issue(ad, addend + o);
-              tl_wait(mm, ad);
+              if (mul_mask) TL<COH>::issue(mm, mul_mask + o);
+              if (addend) TL<COH>::issue(ad, addend + o);
+              TL<COH>::wait(mm, ad);
               v = v * mm + ad;
             }
-            stc4(y + o, v);
+            TL<COH>::st4(y + o, v);
           }
         }
       }
@@ -235,7 +251,7 @@ __device__ __forceinline__ void tok_gemm(const ast_tok_op_t& op, const int wg, c
 // ---- attention core for <= 8 tokens: one wave per (batch, head), lane = feature (misc.hip: attn_fwd_kernel / attn_bwd_kernel)
 constexpr int TOK_MAXL = 8;                      // (a 16-token variant triples the code of this kernel; the model has <= 5 / <= 8)
 // ML = compile-time bound on the token counts (4 or 8): the row loops are fully unrolled over it
-template <int ML>
+template <bool COH, int ML>
 __device__ __forceinline__ void tok_attn_fwd(const ast_tok_op_t& op, const int wg, const int G, const int64_t* d_offset) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int B = op.i[0], H = op.i[1], Lq = op.i[2], Lk = op.i[3], dh = op.i[4], ldq = op.i[5], ldk = op.i[6], ldo = op.i[7];
@@ -253,11 +269,11 @@ __device__ __forceinline__ void tok_attn_fwd(const ast_tok_op_t& op, const int w
 #pragma unroll
     for (int j = 0; j < ML; ++j) {            // every row of K, V and Q in flight together (clamped addresses, masked below)
       const int jk = j < Lk ? j : 0, jq = j < Lq ? j : 0;
-      tl_issue(kv[j], k + ((size_t)b * Lk + jk) * ldk + h * dh + ln);
-      tl_issue(vv[j], v + ((size_t)b * Lk + jk) * ldk + h * dh + ln);
-      tl_issue(qv[j], q + ((size_t)b * Lq + jq) * ldq + h * dh + ln);
+      TL<COH>::issue(kv[j], k + ((size_t)b * Lk + jk) * ldk + h * dh + ln);
+      TL<COH>::issue(vv[j], v + ((size_t)b * Lk + jk) * ldk + h * dh + ln);
+      TL<COH>::issue(qv[j], q + ((size_t)b * Lq + jq) * ldq + h * dh + ln);
     }
-    tl_wait_all(kv); tl_wait_all(vv); tl_wait_all(qv);
+    TL<COH>::wait_all(kv); TL<COH>::wait_all(vv); TL<COH>::wait_all(qv);
 #pragma unroll
     for (int j = 0; j < ML; ++j) {
       kv[j] = (j < Lk && lane < dh) ? kv[j] : 0.f;
@@ -287,16 +303,16 @@ __device__ __forceinline__ void tok_attn_fwd(const ast_tok_op_t& op, const int w
       for (int j = 0; j < ML; ++j) {
         if (j < Lk) {
           const float p = s[j] / den;
-          if (lane == 0) stc1(probs + pbase + j, p);
+          if (lane == 0) TL<COH>::st1(probs + pbase + j, p);
           acc += (pdrop > 0.f ? p * dropout_keep(dbase, pbase + j, pdrop, dkeep) : p) * vv[j];
         }
       }
-      if (lane < dh) stc1(o + ((size_t)b * Lq + iq) * ldo + h * dh + lane, acc);
+      if (lane < dh) TL<COH>::st1(o + ((size_t)b * Lq + iq) * ldo + h * dh + lane, acc);
     }
   }
 }
 
-template <int ML>
+template <bool COH, int ML>
 __device__ __forceinline__ void tok_attn_bwd(const ast_tok_op_t& op, const int wg, const int G, const int64_t* d_offset) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int B = op.i[0], H = op.i[1], Lq = op.i[2], Lk = op.i[3], dh = op.i[4], ldq = op.i[5], ldk = op.i[6], ldo = op.i[7];
@@ -314,12 +330,12 @@ __device__ __forceinline__ void tok_attn_bwd(const ast_tok_op_t& op, const int w
 #pragma unroll
     for (int j = 0; j < ML; ++j) {
       const int jk = j < Lk ? j : 0, jq = j < Lq ? j : 0;
-      tl_issue(kv[j], k + ((size_t)b * Lk + jk) * ldk + h * dh + ln);
-      tl_issue(vv[j], v + ((size_t)b * Lk + jk) * ldk + h * dh + ln);
-      tl_issue(qv[j], q + ((size_t)b * Lq + jq) * ldq + h * dh + ln);
-      tl_issue(dov[j], dout + ((size_t)b * Lq + jq) * ldo + h * dh + ln);
+      TL<COH>::issue(kv[j], k + ((size_t)b * Lk + jk) * ldk + h * dh + ln);
+      TL<COH>::issue(vv[j], v + ((size_t)b * Lk + jk) * ldk + h * dh + ln);
+      TL<COH>::issue(qv[j], q + ((size_t)b * Lq + jq) * ldq + h * dh + ln);
+      TL<COH>::issue(dov[j], dout + ((size_t)b * Lq + jq) * ldo + h * dh + ln);
     }
-    tl_wait_all(kv); tl_wait_all(vv); tl_wait_all(qv); tl_wait_all(dov);
+    TL<COH>::wait_all(kv); TL<COH>::wait_all(vv); TL<COH>::wait_all(qv); TL<COH>::wait_all(dov);
 #pragma unroll
     for (int j = 0; j < ML; ++j) {
       kv[j] = (j < Lk && lane < dh) ? kv[j] : 0.f;
@@ -334,8 +350,8 @@ __device__ __forceinline__ void tok_attn_bwd(const ast_tok_op_t& op, const int w
       const size_t pbase = (((size_t)b * H + h) * Lq + iq) * Lk;
       float dp[ML], p[ML];
 #pragma unroll
-      for (int j = 0; j < ML; ++j) tl_issue(p[j], probs + pbase + (j < Lk ? j : 0));
-      tl_wait_all(p);
+      for (int j = 0; j < ML; ++j) TL<COH>::issue(p[j], probs + pbase + (j < Lk ? j : 0));
+      TL<COH>::wait_all(p);
       float dot = 0.f;
 #pragma unroll
       for (int j = 0; j < ML; ++j) {
@@ -358,14 +374,14 @@ __device__ __forceinline__ void tok_attn_bwd(const ast_tok_op_t& op, const int w
           dkv[j] += ds * qi;
         }
       }
-      if (lane < dh) stc1(dq + ((size_t)b * Lq + iq) * ldq + h * dh + lane, dqi);
+      if (lane < dh) TL<COH>::st1(dq + ((size_t)b * Lq + iq) * ldq + h * dh + lane, dqi);
     }
     if (lane < dh) {
 #pragma unroll
       for (int j = 0; j < ML; ++j)
         if (j < Lk) {
-          stc1(dk + ((size_t)b * Lk + j) * ldk + h * dh + lane, dkv[j]);
-          stc1(dv + ((size_t)b * Lk + j) * ldk + h * dh + lane, dvv[j]);
+          TL<COH>::st1(dk + ((size_t)b * Lk + j) * ldk + h * dh + lane, dkv[j]);
+          TL<COH>::st1(dv + ((size_t)b * Lk + j) * ldk + h * dh + lane, dvv[j]);
         }
     }
   }
@@ -373,6 +389,7 @@ __device__ __forceinline__ void tok_attn_bwd(const ast_tok_op_t& op, const int w
 
 // ---- residual + dropout + LayerNorm on 256-wide token rows, one wave per row (norm.hip: add_drop_ln_fwd256 / bwd256) -----
 //   s = x + dropout(sub)   (x may be null);   y = LayerNorm(s)   (gamma null: s only)
+template <bool COH>
 __device__ __forceinline__ void tok_adln_fwd(const ast_tok_op_t& op, const int wg, const int G, const int64_t* d_offset) {
   constexpr int D = 256;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -388,17 +405,17 @@ __device__ __forceinline__ void tok_adln_fwd(const ast_tok_op_t& op, const int w
   for (int row = wg * 4 + wave; row < rows; row += G * 4) {
     const size_t o = (size_t)row * D + lane * 4;
     f32x4 sv, xv = z;
-    tl_issue(sv, sub + o);
-    if (x) tl_issue(xv, x + o);
-    tl_wait(sv, xv);
+    TL<COH>::issue(sv, sub + o);
+    if (x) TL<COH>::issue(xv, x + o);
+    TL<COH>::wait(sv, xv);
     if (p > 0.f) {
       f32x4 m4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { m4[e] = dropout_keep(base, o + e, p, keep); sv[e] *= m4[e]; }
-      stc4(mask + o, m4);
+      TL<COH>::st4(mask + o, m4);
     }
     const f32x4 s4 = x ? sv + xv : sv;
-    if (s_out) stc4(s_out + o, s4);
+    if (s_out) TL<COH>::st4(s_out + o, s4);
     if (!gamma) continue;
     const float m = wave_sum(s4[0] + s4[1] + s4[2] + s4[3]) / D;
     float qq = 0.f;
@@ -408,12 +425,13 @@ __device__ __forceinline__ void tok_adln_fwd(const ast_tok_op_t& op, const int w
     f32x4 y4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) y4[e] = (s4[e] - m) * r * g4[e] + b4[e];
-    stc4(y + o, y4);
-    if (lane == 0) { stc1(mean + row, m); stc1(rstd + row, r); }
+    TL<COH>::st4(y + o, y4);
+    if (lane == 0) { TL<COH>::st1(mean + row, m); TL<COH>::st1(rstd + row, r); }
   }
 }
 
 //   ds = ds_ext + LayerNorm_bwd(dy; s)   (either term may be absent);   dx = ds;   dsub = ds * mask;   dgamma, dbeta += ...
+template <bool COH>
 __device__ __forceinline__ void tok_adln_bwd(const ast_tok_op_t& op, const int wg, const int G) {
   constexpr int D = 256;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -428,10 +446,10 @@ __device__ __forceinline__ void tok_adln_bwd(const ast_tok_op_t& op, const int w
     const size_t o = (size_t)row * D + lane * 4;
     f32x4 dy4 = z, s4 = z, e4 = z, k4 = f32x4{1.f, 1.f, 1.f, 1.f};
     float m = 0.f, r = 0.f;
-    if (dy) { tl_issue(dy4, dy + o); tl_issue(s4, s + o); tl_issue(m, mean + row); tl_issue(r, rstd + row); }
-    if (ds_ext) tl_issue(e4, ds_ext + o);
-    if (mask) tl_issue(k4, mask + o);
-    tl_wait(dy4, s4, e4, k4); tl_wait(m, r);
+    if (dy) { TL<COH>::issue(dy4, dy + o); TL<COH>::issue(s4, s + o); TL<COH>::issue(m, mean + row); TL<COH>::issue(r, rstd + row); }
+    if (ds_ext) TL<COH>::issue(e4, ds_ext + o);
+    if (mask) TL<COH>::issue(k4, mask + o);
+    TL<COH>::wait(dy4, s4, e4, k4); TL<COH>::wait(m, r);
     f32x4 d4 = e4, xh4 = z;
     if (dy) {
       float a = 0.f, b = 0.f;
@@ -442,13 +460,42 @@ __device__ __forceinline__ void tok_adln_bwd(const ast_tok_op_t& op, const int w
       for (int e = 0; e < 4; ++e) d4[e] += r * (dy4[e] * g4[e] - a - xh4[e] * b);
       accg += dy4 * xh4; accb += dy4;
     }
-    if (dx) stc4(dx + o, d4);
-    if (dsub) stc4(dsub + o, d4 * k4);
+    if (dx) TL<COH>::st4(dx + o, d4);
+    if (dsub) TL<COH>::st4(dsub + o, d4 * k4);
   }
   if (dy && dgamma) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { unsafeAtomicAdd(dgamma + lane * 4 + e, accg[e]); unsafeAtomicAdd(dbeta + lane * 4 + e, accb[e]); }
   }
+}
+
+template <bool COH>
+__device__ __forceinline__ void tok_run_op(const ast_tok_op_t& op, const int wg, const int G, unsigned char* lds, const int64_t* d_offset) {
+  switch (op.type) {
+    case AST_TOK_GEMM: {
+      const int M = op.i[0];
+      if (M <= 16) tok_gemm<COH, 1>(op, wg, G, lds, d_offset);
+      else if (M <= 32) tok_gemm<COH, 2>(op, wg, G, lds, d_offset);
+      else tok_gemm<COH, 4>(op, wg, G, lds, d_offset);
+    } break;
+    case AST_TOK_ATTN_FWD: {
+      const int ml = max(op.i[2], op.i[3]);
+      if (ml <= 4) tok_attn_fwd<COH, 4>(op, wg, G, d_offset); else tok_attn_fwd<COH, 8>(op, wg, G, d_offset);
+    } break;
+    case AST_TOK_ATTN_BWD: {
+      const int ml = max(op.i[2], op.i[3]);
+      if (ml <= 4) tok_attn_bwd<COH, 4>(op, wg, G, d_offset); else tok_attn_bwd<COH, 8>(op, wg, G, d_offset);
+    } break;
+    case AST_TOK_ADLN_FWD: tok_adln_fwd<COH>(op, wg, G, d_offset); break;
+    case AST_TOK_ADLN_BWD: tok_adln_bwd<COH>(op, wg, G); break;
+    default: break;
+  }
+}
+
+// One launch per op (G = the op's task count): the same op bodies behind ordinary kernel boundaries.
+__global__ __launch_bounds__(256) void tok_op_kernel(const ast_tok_op_t op, const int64_t* __restrict__ d_offset) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tok_lds[];
+  tok_run_op<false>(op, blockIdx.x, gridDim.x, tok_lds, d_offset);
 }
 
 #ifdef AST_STAMPS
@@ -488,25 +535,7 @@ __global__ __launch_bounds__(256) void tok_program_kernel(const TokProgram prog,
   for (int k = 0; k < prog.nops; ++k) {
     const ast_tok_op_t& op = prog.op[k];
     TOK_STAMP(0);
-    switch (op.type) {
-      case AST_TOK_GEMM: {
-        const int M = op.i[0];
-        if (M <= 16) tok_gemm<1>(op, wg, G, tok_lds, d_offset);
-        else if (M <= 32) tok_gemm<2>(op, wg, G, tok_lds, d_offset);
-        else tok_gemm<4>(op, wg, G, tok_lds, d_offset);
-      } break;
-      case AST_TOK_ATTN_FWD: {
-        const int ml = max(op.i[2], op.i[3]);
-        if (ml <= 4) tok_attn_fwd<4>(op, wg, G, d_offset); else tok_attn_fwd<8>(op, wg, G, d_offset);
-      } break;
-      case AST_TOK_ATTN_BWD: {
-        const int ml = max(op.i[2], op.i[3]);
-        if (ml <= 4) tok_attn_bwd<4>(op, wg, G, d_offset); else tok_attn_bwd<8>(op, wg, G, d_offset);
-      } break;
-      case AST_TOK_ADLN_FWD: tok_adln_fwd(op, wg, G, d_offset); break;
-      case AST_TOK_ADLN_BWD: tok_adln_bwd(op, wg, G); break;
-      default: break;
-    }
+    tok_run_op<true>(op, wg, G, tok_lds, d_offset);
     TOK_STAMP(1);
     if (!(op.flags & AST_TOK_NO_BARRIER) && k + 1 < prog.nops) grid_barrier(bar);
     TOK_STAMP(2);
@@ -531,7 +560,8 @@ extern "C" int ast_debug_read_tok_stamps(unsigned long long* host) {
 extern "C" int ast_tok_program(const ast_tok_op_t* ops, int nops, int G, int xcd, void* sync, int* status, const int64_t* d_offset,
                                void* stream) {
   if (!ops || nops <= 0 || nops > TOK_MAXOPS) AST_FAIL("ast_tok_program: 1..%d ops per launch (got %d)", TOK_MAXOPS, nops);
-  if (G <= 0 || G > 32 || xcd < 0 || xcd > 7 || !sync || !status) AST_FAIL("ast_tok_program: bad G / xcd / sync / status");
+  const bool per_op = G <= 0;                   // G <= 0: one ordinary launch per op
+  if (!per_op && (G > 32 || xcd < 0 || xcd > 7 || !sync || !status)) AST_FAIL("ast_tok_program: bad G / xcd / sync / status");
   TokProgram prog;
   prog.nops = nops; prog.G = G; prog.xcd = xcd; prog.pad = 0;
   for (int k = 0; k < nops; ++k) {
@@ -561,6 +591,23 @@ extern "C" int ast_tok_program(const ast_tok_op_t* ops, int nops, int G, int xcd
   if (!attr_set) {
     AST_HIP(hipFuncSetAttribute((const void*)tok_program_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tok_lds_bytes(4)));
     attr_set = true;
+  }
+  if (per_op) {
+    static bool attr1 = false;
+    if (!attr1) {
+      AST_HIP(hipFuncSetAttribute((const void*)tok_op_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tok_lds_bytes(4)));
+      attr1 = true;
+    }
+    for (int k = 0; k < nops; ++k) {
+      const ast_tok_op_t& op = ops[k];
+      int grid = 1, l = 0;
+      if (op.type == AST_TOK_GEMM) { grid = op.i[1] / 16; l = tok_lds_bytes(op.i[0] <= 16 ? 1 : (op.i[0] <= 32 ? 2 : 4)); }
+      else if (op.type == AST_TOK_ATTN_FWD || op.type == AST_TOK_ATTN_BWD) grid = (op.i[0] * op.i[1] + 3) / 4;
+      else grid = (op.i[0] + 3) / 4;
+      hipLaunchKernelGGL(tok_op_kernel, dim3(grid), dim3(256), l, (hipStream_t)stream, op, d_offset);
+      AST_CHECK_LAUNCH();
+    }
+    return 0;
   }
   hipLaunchKernelGGL(tok_program_kernel, dim3(16 * G), dim3(256), lds, (hipStream_t)stream, prog, (unsigned*)sync, status, d_offset);
   AST_CHECK_LAUNCH();

@@ -1,5 +1,6 @@
-"""Token programs (ast_tok_program: transformer stacks in a few launches, csrc/tokprog.hip; experimental, off by default:
-config.tok_programs / AST_TOK_PROGRAMS=1) against the per-operator path they replace (ast_skinny_gemm / ast_attn_* / ast_add_drop_ln_*, themselves checked against the oracle in
+"""Token op lists (ast_tok_program, csrc/tokprog.hip, ast_amd/tokprog.py: one autograd node per transformer STACK) against
+the per-operator path they replace, in both execution modes (config.tok_programs / AST_TOK_PROGRAMS: 1 = one launch per
+op, the default; 2 = persistent program launches, experimental) (ast_skinny_gemm / ast_attn_* / ast_add_drop_ln_*, themselves checked against the oracle in
 test_gpu_ops.py / test_gpu_models.py): same outputs, same input and parameter gradients, to f32 re-association noise."""
 import pytest
 import torch
@@ -32,7 +33,7 @@ def _model(ctor, tag, p_drop):
 
 def _run(m, fn, use_programs):
     old = config.tok_programs
-    config.tok_programs = use_programs
+    config.tok_programs = int(use_programs)
     try:
         for p in m.parameters():
             p.grad = None
@@ -46,8 +47,9 @@ def _run(m, fn, use_programs):
         config.tok_programs = old
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("B,L", [(8, 3), (8, 2), (2, 2), (16, 4), (4, 1), (7, 8)])
-def test_encoder_stacks_match_per_operator_path(B, L):
+def test_encoder_stacks_match_per_operator_path(B, L, mode):
     """The TransformerEncoder stacks of StyleEncoder (CLS token: L = S + 1) and ContentEncoder (L = S) on a random token
     sequence, dropout off: output, input gradient and every parameter gradient."""
     from ast_amd.style_encoder import _module_bank
@@ -68,8 +70,8 @@ def test_encoder_stacks_match_per_operator_path(B, L):
                 for lyr in mm._layers:
                     out = lyr(out, True)
             return [out], [seq]
-        o1, i1, g1 = _run(m, fn, True)
-        o0, i0, g0 = _run(m, fn, False)
+        o1, i1, g1 = _run(m, fn, mode)
+        o0, i0, g0 = _run(m, fn, 0)
         assert rel_l2(o1[0], o0[0]) < 1e-5
         assert rel_l2(i1[0], i0[0]) < 2e-4
         assert set(g1) == set(g0) and len(g0) >= 4 * 12
@@ -78,8 +80,9 @@ def test_encoder_stacks_match_per_operator_path(B, L):
     tokprog.check_status()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("B,S", [(8, 2), (2, 4), (16, 3)])
-def test_decoder_stack_matches_per_operator_path(B, S):
+def test_decoder_stack_matches_per_operator_path(B, S, mode):
     """The TransformerDecoder stack (pre-norm, causal self-attention, cross-attention over the 2 S memory rows) with
     gradients to the target embeddings, the memory and every parameter."""
     config.set_compute_dtype(torch.float32)
@@ -92,8 +95,8 @@ def test_decoder_stack_matches_per_operator_path(B, S):
         tgt, mem = tgt0.clone().requires_grad_(True), mem0.clone().requires_grad_(True)
         mm._prepare()
         return [mm._stack(tgt, mem)], [tgt, mem]
-    o1, i1, g1 = _run(m, fn, True)
-    o0, i0, g0 = _run(m, fn, False)
+    o1, i1, g1 = _run(m, fn, mode)
+    o0, i0, g0 = _run(m, fn, 0)
     assert rel_l2(o1[0], o0[0]) < 1e-5
     for a, b in zip(i1, i0):
         assert rel_l2(a, b) < 2e-4
@@ -103,7 +106,8 @@ def test_decoder_stack_matches_per_operator_path(B, S):
     tokprog.check_status()
 
 
-def test_stack_programs_with_dropout_are_consistent():
+@pytest.mark.parametrize("mode", [1, 2])
+def test_stack_programs_with_dropout_are_consistent(mode):
     """Dropout on: the masks drawn inside the program (attention probabilities, residual branches, FFN hidden units) are
     the ones its backward uses -- checked through the directional derivative of the loss along a random input
     perturbation, which only holds if forward and backward agree on every mask."""
@@ -129,7 +133,7 @@ def test_stack_programs_with_dropout_are_consistent():
             return float(loss), tgt.grad.detach().clone()
         return float(loss), None
     old = config.tok_programs
-    config.tok_programs = True
+    config.tok_programs = mode
     try:
         _, grad = loss_at(tgt0, True)
         assert tokprog.decoder_stack_ok(tgt0, mem0, m._layers)

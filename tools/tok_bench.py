@@ -14,7 +14,7 @@ dev = "cuda"
 config.set_compute_dtype(torch.bfloat16)
 
 def bench(name, build):
-    for mode in (False, True):
+    for mode in (0, 1, 2):
         config.tok_programs = mode
         fn = build()
         for _ in range(3): fn()
@@ -33,7 +33,7 @@ def bench(name, build):
         e0.record()
         for _ in range(20): g.replay()
         e1.record(); torch.cuda.synchronize()
-        print(f"{name:28s} {'token programs' if mode else 'per operator  '}: {e0.elapsed_time(e1) * 1000 / 20:8.1f} us per forward+backward", flush=True)
+        print(f"{name:28s} {('per operator (autograd node each)', 'stack node, one launch per op   ', 'stack node, persistent programs  ')[mode]}: {e0.elapsed_time(e1) * 1000 / 20:8.1f} us per forward+backward", flush=True)
     tokprog.check_status()
 
 def enc(ctor, L):
@@ -42,7 +42,7 @@ def enc(ctor, L):
         seq = torch.randn(B, L, 256, device=dev, requires_grad=True)
         def fn():
             _module_bank(m).prepare(True)
-            if config.tok_programs:
+            if config.tok_programs > 0:
                 out = tokprog.encoder_stack(seq, m._layers, True, 0)
             else:
                 out = seq
