@@ -91,7 +91,7 @@ class FlatGroup:
     def zero_grad(self):
         self.flat_g.zero_()
 
-    def all_reduce(self, world, wire_dtype=torch.float32):
+    def all_reduce(self, world, wire_dtype=torch.float32, force=False):
         """Mean of the flat gradient over ranks: ONE collective per group.  wire_dtype=bf16 halves the bytes on the
         xGMI ring (124 MB -> 62 MB for encoders+decoder; the all-reduce sits on the critical path between backward and
         Adam): cast kernel -> all-reduce -> cast back + scale.  Used in the bf16 compute mode only."""
@@ -99,6 +99,15 @@ class FlatGroup:
 
         def scale(t, s):
             check(lib().ast_scale(ptr(t), None, s, ptr(t), t.numel(), 0, stream()), "ast_scale")
+        if force and world <= 1:                       # one-rank rehearsal of the collective path (tests): the same calls
+            if wire_dtype == torch.bfloat16 and self.n >= (1 << 20):
+                if getattr(self, "_wire", None) is None:
+                    self._wire = torch.empty(self.n, dtype=torch.bfloat16, device=self.flat_g.device)
+                self._wire.zero_()
+                dist.all_reduce(self._wire, op=dist.ReduceOp.SUM)      # (the gradient itself stays f32-exact: the wire is a dummy here)
+            else:
+                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+            return
         if world > 1 and wire_dtype == torch.bfloat16 and self.n >= (1 << 20):
             if getattr(self, "_wire", None) is None:
                 self._wire = torch.empty(self.n, dtype=torch.bfloat16, device=self.flat_g.device)
@@ -161,6 +170,13 @@ class Trainer:
         if self._matched:
             ops.set_sync_bn(world)
             self.cfg = dataclasses.replace(self.cfg, use_graph=False, multi_stream=False)
+        # Data parallel, default mode: the two gradient all-reduces are RCCL calls INSIDE the captured step (stream-ordered,
+        # capturable through torch's NCCL process group), so world > 1 replays ONE graph with the discriminator phase
+        # overlapped, exactly as one GPU does, instead of three graphs with eager collectives between them.  A probe
+        # capture of a small all-reduce decides (any failure -> the three-graph form); AST_DIST_IN_GRAPH=0 turns it off.
+        self._force_coll = os.environ.get("AST_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
+        self._dist = world > 1 or self._force_coll
+        self._dist_in_graph = None                   # decided at the first graph step (probe)
         self._glob = None
         self._stream_d = None
         self._graphs = {}
@@ -357,6 +373,8 @@ class Trainer:
         sd.wait_stream(main)
         with torch.cuda.stream(sd):
             d_loss = self._d_phase(style_emb, class_emb, content_emb, labels_host)
+            if self._dist:
+                self.D.all_reduce(self.world, force=self._force_coll)
             self.D.adam(c.lr_d, c.betas, c.eps, c.max_grad_norm)
             self.D.zero_grad()
         d_loss.record_stream(main)
@@ -364,18 +382,63 @@ class Trainer:
         # created before them, their backward ran after the decoder's and held the three encoder branches back (+0.9 ms)
         self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb, before_adv=lambda: main.wait_stream(sd), side=sd)
         self._parts["adv_d"] = d_loss.detach()
+        if self._dist:
+            self.G.all_reduce(self.world, self._wire_dtype, force=self._force_coll)
         if c.keep_grads:
             self.last_grad_g = self.G.flat_g.clone()
         self.G.adam(c.lr_g, c.betas, c.eps, c.max_grad_norm)
         return self._parts
 
+    def _one_graph(self):
+        """The step as ONE captured graph: a single GPU, or data parallel with the collectives inside the graph."""
+        if self.cfg.segmented or self._matched:
+            return False
+        if not self._dist:
+            return self.world == 1
+        return bool(self._dist_in_graph) and self.cfg.multi_stream and self.cfg.overlap_d
+
+    def _probe_collective_capture(self):
+        """Can this process group's all-reduce be captured into a hipGraph and replayed?  Decided once, by doing it on
+        a small tensor; every rank runs the same collectives, and the ranks agree on the outcome (MIN) at the end."""
+        if os.environ.get("AST_DIST_IN_GRAPH", "1") == "0" or not self.cfg.use_graph or dist.get_backend() != "nccl":
+            return False
+        ok = 1.0
+        try:
+            t = torch.ones(4096, device=self.device)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dist.all_reduce(t)                       # communicator set-up happens outside the capture
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):     # (the process group's watchdog thread polls events meanwhile)
+                dist.all_reduce(t)
+            t.fill_(1.0)
+            g.replay()
+            torch.cuda.synchronize()
+            if abs(float(t[0]) - dist.get_world_size()) > 1e-3:
+                ok = 0.0
+        except Exception as e:                           # noqa: BLE001 -- any failure means "use the three-graph form"
+            print(f"[ast_amd] all-reduce inside a captured graph is not available ({type(e).__name__}: {e}); using three graphs", flush=True)
+            ok = 0.0
+            try:
+                torch.cuda.synchronize()
+            except Exception:                            # noqa: BLE001
+                pass
+        flag = torch.tensor([ok], device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
+
     def _step_body(self, x, labels_host):
-        if self.world == 1 and not self.cfg.segmented and self.cfg.multi_stream and self.cfg.overlap_d:
+        if self._one_graph() and self.cfg.multi_stream and self.cfg.overlap_d:
             return self._step_overlapped(x, labels_host)
         self._seg_a(x, labels_host)
-        self.D.all_reduce(self.world)
+        if self._dist:
+            self.D.all_reduce(self.world, force=self._force_coll)
         self._seg_b(x, labels_host)
-        self.G.all_reduce(self.world, self._wire_dtype)
+        if self._dist:
+            self.G.all_reduce(self.world, self._wire_dtype, force=self._force_coll)
         if self.cfg.keep_grads:
             self.last_grad_g = self.G.flat_g.clone()
         self._seg_c(x, labels_host)
@@ -419,10 +482,12 @@ class Trainer:
         """x: (B,S,2,287,597) f32 on the device; labels on the HOST (balanced [0]*B/2+[1]*B/2 as
         dataloader.py:143-146 builds them).  Returns a dict of detached device scalars."""
         assert not labels_host.is_cuda, "pass labels on the host: avoids a device sync per step"
+        if self._dist and self._dist_in_graph is None:
+            self._dist_in_graph = False if self._matched else self._probe_collective_capture()
         if not self.cfg.use_graph:
             self.losses = self._step_body(x, labels_host)
             return self.losses
-        segmented = self.world > 1 or self.cfg.segmented
+        segmented = not self._one_graph()
         key = self._graph_key(x, labels_host, segmented)
         if key not in self._graphs:
             self._capture(key, x, labels_host, segmented)
@@ -431,11 +496,13 @@ class Trainer:
             static_x.copy_(x)
         if not segmented:
             graphs[0].replay()
-        else:                                   # data parallel: the two flat-gradient all-reduces run between replays
+        else:                                   # data parallel, three-graph form: the two flat-gradient all-reduces run between replays
             graphs[0].replay()
-            self.D.all_reduce(self.world)
+            if self._dist:
+                self.D.all_reduce(self.world, force=self._force_coll)
             graphs[1].replay()
-            self.G.all_reduce(self.world, self._wire_dtype)
+            if self._dist:
+                self.G.all_reduce(self.world, self._wire_dtype, force=self._force_coll)
             graphs[2].replay()
         self.losses = outs
         return outs
@@ -495,7 +562,7 @@ class Trainer:
         torch.cuda.synchronize()
         if not segmented:
             gph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gph):
+            with torch.cuda.graph(gph, **({"capture_error_mode": "thread_local"} if self._dist else {})):
                 outs = self._step_body(static_x, labels_host)
             graphs = [gph]
         else:

@@ -362,6 +362,7 @@ def main():
                                   + ", all losses, D and G phases, grad clip, Adam",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": tr.cfg.use_graph,
                       "grad_allreduce": ("bf16" if tr._wire_dtype == torch.bfloat16 else "f32") if world > 1 else None,
+                      "collectives": (("captured inside the step's graph" if tr._dist_in_graph else "eager, between three graphs") if tr.cfg.use_graph else "eager") if world > 1 else None,
                       "dp_semantics": ("global-batch (sync-BN + gathered losses)" if args.loss_matched and world > 1 else "per-rank BN and batch-coupled losses")},
            "losses": losses}
     if rank == 0 and world == 1 and args.infer and args.decoder == "new":

@@ -299,3 +299,29 @@ def test_mixed_length_stream_vs_oracle():
             tol = (6e-2 if k == "hsic" else 2e-2) if i > 0 else 2e-3
             assert math.isclose(got[k], ref[k], rel_tol=tol, abs_tol=2e-4), (i, seconds, k, got[k], ref[k])
     assert len(tr._graphs) == 3                            # one capture per length bucket; revisits replay
+
+
+def test_collectives_inside_the_captured_step_one_rank():
+    """Data parallel, default mode: the two gradient all-reduces are RCCL calls captured INSIDE the step's graph (world > 1
+    then replays one graph, like a single GPU).  One-rank rehearsal on this box: a 1-rank NCCL group, the collective path
+    forced on (AST_FORCE_COLLECTIVES=1): the probe must accept, the step must be ONE graph, and three steps must give the
+    losses of a plain single-GPU trainer (an all-reduce over one rank is the identity)."""
+    import torch.distributed as dist
+    ast_amd.set_compute_dtype(torch.bfloat16)
+    x, labels = train.synthetic_batch(2, 2, "cuda:0")
+    ref = train.Trainer(train.TrainConfig(dropout=False), device="cuda:0")
+    ref_losses = [float(ref.step(x, labels)["total"]) for _ in range(3)]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", AST_FORCE_COLLECTIVES="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        tr = train.Trainer(train.TrainConfig(dropout=False), device="cuda:0")
+        assert tr._dist and tr._force_coll
+        losses = [float(tr.step(x, labels)["total"]) for _ in range(3)]
+        assert tr._dist_in_graph is True, "the probe refused all-reduce capture on this stack"
+        (graphs, _, _), = tr._graphs.values()
+        assert len(graphs) == 1
+        for a, b in zip(losses, ref_losses):
+            assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (losses, ref_losses)
+    finally:
+        os.environ.pop("AST_FORCE_COLLECTIVES", None)
+        dist.destroy_process_group()
