@@ -160,10 +160,14 @@ def _plan(N, H, W, Cs, Cd, k, stride, pad, dtype, transposed=False):
     (32, 64, 3, 2, 18, 38, 2),      # stride 2: forward on the gathered kernel, the data gradient's parity classes on patches
     (64, 32, 3, 2, 21, 45, 2),
 ])
-def test_conv2d_patch_kernel(dtype, cin, cout, k, stride, H, W, N):
+@pytest.mark.parametrize("nf", [None, 12])
+def test_conv2d_patch_kernel(dtype, cin, cout, k, stride, H, W, N, nf):
     """The same checks as test_conv2d_fwd_bwd with the patch-staged kernel forced on small shapes (it is selected by
-    tile count in production), plus a direct comparison of its output with the gathered kernel's."""
-    with _env(AST_PCONV_MIN_TILES=1):
+    tile count in production), plus a direct comparison of its output with the gathered kernel's.  nf = 12 forces the
+    12-fragment 2-D tiles (12x16 / 6x32 / 3x64 pixels) that production picks for single-round grids."""
+    if nf is not None and (stride != 1 or H < 12):
+        pytest.skip("12-fragment 2-D tiles: stride-1 layers with room for them")
+    with _env(AST_PCONV_MIN_TILES=1, **({} if nf is None else {"AST_PCONV_NF": nf})):
         ops._ws_cache.clear()
         if stride == 1:
             assert _plan(N, H, W, ops.pad8(cin), ops.pad8(cout), k, stride, 1, dtype)[2] < 0      # the patch kernel is what runs
