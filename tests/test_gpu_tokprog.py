@@ -107,43 +107,52 @@ def test_decoder_stack_matches_per_operator_path(B, S, mode):
 
 
 @pytest.mark.parametrize("mode", [1, 2])
-def test_stack_programs_with_dropout_are_consistent(mode):
-    """Dropout on: the masks drawn inside the program (attention probabilities, residual branches, FFN hidden units) are
-    the ones its backward uses -- checked through the directional derivative of the loss along a random input
-    perturbation, which only holds if forward and backward agree on every mask."""
+def test_stacks_with_dropout_match_per_operator_path(mode):
+    """Dropout on (attention probabilities, residual branches, FFN hidden units): the op lists draw their masks from the same
+    (seed, call number, element index) streams as the per-operator kernels, so with the call counter rewound the two paths
+    must agree -- outputs AND gradients -- which also proves that the backward ops use the masks their forward drew."""
+    from ast_amd import ops
+    from ast_amd.style_encoder import _module_bank
     config.set_compute_dtype(torch.float32)
-    m = _model(ast_amd.Decoder, "decoder", 0.1)
-    B, S = 8, 2
     g = torch.Generator().manual_seed(9)
+    B, S = 8, 2
     tgt0 = torch.randn(B, S, 256, generator=g).to(DEV)
     mem0 = torch.randn(B, 2 * S, 256, generator=g).to(DEV)
-    d_t = torch.randn(B, S, 256, generator=g).to(DEV)
-    wts = torch.randn(B, S, 256, generator=g).to(DEV)
-    from ast_amd import ops
+    seq0 = torch.randn(B, S + 1, 256, generator=g).to(DEV)
+    ops._DropState.counter = torch.full((1,), 37, dtype=torch.int64, device=DEV)       # a step counter in mid-training
 
-    def loss_at(t, want_grad):
-        ops._DropState.calls = 1000                                   # the same seeds -> the same masks in every evaluation
-        tgt = t.clone().requires_grad_(want_grad)
-        mem = mem0.clone()
-        m._prepare()
-        out = m._stack(tgt, mem)
-        loss = (out * wts).sum()
-        if want_grad:
-            loss.backward()
-            return float(loss), tgt.grad.detach().clone()
-        return float(loss), None
-    old = config.tok_programs
-    config.tok_programs = mode
-    try:
-        _, grad = loss_at(tgt0, True)
-        assert tokprog.decoder_stack_ok(tgt0, mem0, m._layers)
-        eps = 1e-2
-        with torch.no_grad():
-            lp, _ = loss_at(tgt0 + eps * d_t, False)
-            lm, _ = loss_at(tgt0 - eps * d_t, False)
-    finally:
-        config.tok_programs = old
-    fd = (lp - lm) / (2 * eps)
-    an = float((grad * d_t).sum())
-    assert abs(fd - an) <= 2e-2 * max(abs(an), 1.0), (fd, an)
+    dec = _model(ast_amd.Decoder, "decoder", 0.1)
+    enc = _model(ast_amd.StyleEncoder, "style", 0.1)
+
+    def dec_fn(mm):
+        ops._DropState.calls = 1000
+        tgt, mem = tgt0.clone().requires_grad_(True), mem0.clone().requires_grad_(True)
+        mm._prepare()
+        return [mm._stack(tgt, mem)], [tgt, mem]
+
+    def enc_fn(mm):
+        ops._DropState.calls = 2000
+        seq = seq0.clone().requires_grad_(True)
+        _module_bank(mm).prepare(True)
+        if config.tok_programs > 0:
+            out = tokprog.encoder_stack(seq, mm._layers, True, 0)
+        else:
+            out = seq
+            for lyr in mm._layers:
+                out = lyr(out, True)
+        return [out], [seq]
+    for m, fn in ((dec, dec_fn), (enc, enc_fn)):
+        o1, i1, g1 = _run(m, fn, mode)
+        o0, i0, g0 = _run(m, fn, 0)
+        assert rel_l2(o1[0], o0[0]) < 1e-5
+        for a, b in zip(i1, i0):
+            assert rel_l2(a, b) < 2e-4
+        assert set(g1) == set(g0) and g0
+        for k in g0:
+            assert rel_l2(g1[k], g0[k]) < 2e-4, k
+    # and the masks were really there: the same call with dropout off gives another output
+    off = _model(ast_amd.Decoder, "decoder", 0.0)
+    o_off, _, _ = _run(off, dec_fn, mode)
+    o_on, _, _ = _run(dec, dec_fn, mode)
+    assert rel_l2(o_on[0], o_off[0]) > 1e-2
     tokprog.check_status()
