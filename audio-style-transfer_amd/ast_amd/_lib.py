@@ -30,7 +30,7 @@ class WeightDesc(C.Structure):
     """ast_weight_desc_t"""
     _fields_ = [("w", vp), ("u", vp), ("v", vp), ("sigma", vp), ("scratch", vp), ("wf", vp), ("wb", vp)] + \
                [(n, i32) for n in ("Co", "Ci", "KK", "s_co", "s_ci", "Cop", "Cip", "power_iter")] + \
-               [("dwp", vp), ("grad", vp), ("inner", vp), ("dwp_from_wb", i32), ("pad_", i32)]
+               [("dwp", vp), ("grad", vp), ("inner", vp), ("dwp_from_wb", i32), ("dwp_replicas", i32)]
 
 
 class LinWg(C.Structure):
@@ -106,6 +106,7 @@ _SIGS = {
     "ast_cqt_octaves": ([vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, vp], i32),
     "ast_cqt_sections": ([vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "ast_resample_poly": ([vp, i32, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp], i32),
+    "ast_wgrad_rep": ([vp, vp, vp, C.POINTER(Gather), i32, i32, vp], i32),
     "ast_tok_max_ops": ([], i32),
     "ast_tok_program": ([vp, i32, i32, i32, vp, vp, vp, vp], i32),
 }

@@ -36,3 +36,6 @@ bn_mask_from_preact = _os.environ.get("AST_BN_MASK_FROM_PREACT", "1") != "0"
 # BatchNorm backward sums accumulated in the epilogue of the data-gradient GEMM that produces the layer's dy
 # (AST_FUSED_BN_BWD=0 keeps the separate pass over dy and x).
 fused_bn_bwd = _os.environ.get("AST_FUSED_BN_BWD", "1") != "0"
+
+# copies of the weight-gradient staging of small (pixel-rich) conv layers that ast_wgrad_rep spreads its atomics over
+wgrad_replicas = int(_os.environ.get("AST_WGRAD_REPLICAS", "8"))

@@ -55,17 +55,22 @@ class WeightBank:
         self.max_co = self.max_cols = self.max_packed = 1
         # packed f32 gradient staging for every conv / conv-transpose weight: ONE arena, zeroed by the
         # pack kernel of each training forward, unpacked by ONE batched launch pair after backward
-        sizes = []
+        # Small weights belong to the pixel-rich layers, whose weight-gradient kernels end with ~85 workgroups adding one tile
+        # each into the same addresses (f32 atomics serialise: 14 us of a 40 us launch).  They get WGRAD_REPLICAS copies of
+        # their staging; ast_wgrad_rep spreads the workgroups over them and the flush sums the copies.
+        sizes, reps = [], []
         for (w, kind, *_rest) in self.specs:
             if kind == "linear":
-                sizes.append(0)
+                sizes.append(0); reps.append(1)
             else:
                 co, ci = (w.shape[0], w.shape[1]) if kind == "conv" else (w.shape[1], w.shape[0])
-                sizes.append(pad8(co) * w.shape[2] * w.shape[3] * pad8(ci))
+                one = pad8(co) * w.shape[2] * w.shape[3] * pad8(ci)
+                r = config.wgrad_replicas if (config.wgrad_replicas > 1 and one <= (1 << 18)) else 1
+                sizes.append(one * r); reps.append(r)
         if training and (getattr(self, "dw_arena", None) is None or self.dw_arena.device != dev):
             self.dw_arena = torch.zeros(max(1, sum(sizes)), dtype=torch.float32, device=dev)
         off = 0
-        for e, (w, kind, dtype_fn, u, v, bias, rows), sz in zip(self.entries, self.specs, sizes):
+        for e, (w, kind, dtype_fn, u, v, bias, rows), sz, rep in zip(self.entries, self.specs, sizes, reps):
             dt = dtype_fn()
             if kind == "conv":
                 Co, Ci, k, _ = w.shape
@@ -92,7 +97,7 @@ class WeightBank:
             # inference session between two training steps must not invalidate the training descriptors
             grad_ptr = None
             if training:
-                e.dwp = None
+                e.dwp, e.replicas = None, rep
                 if sz:
                     e.dwp = self.dw_arena[off:off + sz]
                     off += sz
@@ -100,7 +105,7 @@ class WeightBank:
             descs.append(WeightDesc(w=w.data_ptr() + 4 * w_off, u=ptr(u), v=ptr(v), sigma=ptr(e.sigma), scratch=ptr(e.scratch),
                                     wf=ptr(e.wf), wb=ptr(e.wb), Co=Co, Ci=Ci, KK=KK, s_co=s_co, s_ci=s_ci, Cop=e.Cop, Cip=e.Cip,
                                     power_iter=1 if training else 0, dwp=ptr(e.dwp), grad=grad_ptr, inner=ptr(e.gtmp),
-                                    dwp_from_wb=1 if kind == "convT" else 0, pad_=0))
+                                    dwp_from_wb=1 if kind == "convT" else 0, dwp_replicas=rep if training else 1))
             dts.append(dcode(dt))
             self.max_co = max(self.max_co, Co)
             self.max_cols = max(self.max_cols, Ci * KK)

@@ -159,11 +159,14 @@ def _igemm(src, wgt, bias, dst, g, flags=0, stats=None, bn=None, per_image=False
         PROFILE.append((f"igemm_kernel<{dt},{_igemm_config(g, dcode(src.dtype))}>", fl, by, e0, e1))
 
 
-def _wgrad(dy, src, dwp, g):
+def _wgrad(dy, src, dwp, g, replicas=1):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib().ast_wgrad(ptr(dy), ptr(src), ptr(dwp), g, dcode(src.dtype), stream()), "ast_wgrad")
+    if replicas > 1:                               # dwp holds `replicas` zeroed copies; the bank's flush sums them
+        check(lib().ast_wgrad_rep(ptr(dy), ptr(src), ptr(dwp), g, dcode(src.dtype), int(replicas), stream()), "ast_wgrad_rep")
+    else:
+        check(lib().ast_wgrad(ptr(dy), ptr(src), ptr(dwp), g, dcode(src.dtype), stream()), "ast_wgrad")
     if PROFILE is not None:
         e1.record()
         fl, by = _gemm_cost(g, src.element_size(), wgrad=True)
@@ -183,10 +186,11 @@ class PackedWeight:
     """One GEMM weight of a model: the f32 master parameter (PyTorch layout),
     optional spectral-norm buffers and its two packed images (see WeightBank)."""
     __slots__ = ("weight", "u", "v", "bias", "Co", "Ci", "KK", "s_co", "s_ci", "Cop", "Cip", "dtype", "wf", "wb",
-                 "sigma", "scratch", "bias_pad", "w_off", "b_off", "transposed", "gtmp", "dwp", "bank")
+                 "sigma", "scratch", "bias_pad", "w_off", "b_off", "transposed", "gtmp", "dwp", "bank", "replicas")
 
     def __init__(self):
         self.wf = self.wb = self.dwp = self.bank = None
+        self.replicas = 1
 
     def bias_ptr_tensor(self):
         if self.bias is None:
@@ -237,7 +241,7 @@ class Conv2dFn(torch.autograd.Function):
         N, H, W, Cs = x.shape
         if pw.dwp is None:
             raise RuntimeError("weights were prepared in eval/no-grad mode; run the forward in training mode before backward")
-        _wgrad(dy, x, pw.dwp, ctx.geom)           # into the per-model staging arena; unpacked once after backward
+        _wgrad(dy, x, pw.dwp, ctx.geom, pw.replicas)           # into the per-model staging arena; unpacked once after backward
         pw.bank.request_flush()
         if ctx.bias_grad:
             pw.add_bias_grad(dy)
@@ -292,8 +296,8 @@ class ResHeadFn(torch.autograd.Function):
         N, H, W, Cs = x.shape
         if pw1.dwp is None or pwd.dwp is None:
             raise RuntimeError("weights were prepared in eval/no-grad mode; run the forward in training mode before backward")
-        _wgrad(dc1, x, pw1.dwp, g1)
-        _wgrad(didn, x, pwd.dwp, gd)
+        _wgrad(dc1, x, pw1.dwp, g1, pw1.replicas)
+        _wgrad(didn, x, pwd.dwp, gd, pwd.replicas)
         pw1.bank.request_flush()                 # both convs feed a normalisation: their biases carry no gradient
         dx = None
         if ctx.needs_input_grad[0]:
@@ -334,7 +338,7 @@ class ConvT2dFn(torch.autograd.Function):
         assert (Hx, Wx) == (H, W), "ConvTranspose2d geometry mismatch"
         if pw.dwp is None:
             raise RuntimeError("weights were prepared in eval/no-grad mode; run the forward in training mode before backward")
-        _wgrad(x, dy, pw.dwp, g)
+        _wgrad(x, dy, pw.dwp, g, pw.replicas)
         pw.bank.request_flush()
         if ctx.bias_grad:
             pw.add_bias_grad(dy)

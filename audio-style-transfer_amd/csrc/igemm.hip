@@ -616,6 +616,19 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
 // images; the MFMA operands need [channel][pixel]: bf16 through ds_read_b64_tr_b16 (hardware
 // transpose), f32 through ds_read_b32 (one element per lane per MFMA).
 // ---------------------------------------------------------------------------
+#ifdef AST_STAMPS
+__device__ unsigned long long ast_wg_stamps[4096 * 8];      // wgrad_kernel phase stamps (tools/wgrad_stamps.py)
+#define WG_STAMP(k) do { if (threadIdx.x == 0 && tix < 4096) ast_wg_stamps[tix * 8 + (k)] = (k) >= 6 ? wall_clock64() : __builtin_readcyclecounter(); } while (0)
+#else
+#define WG_STAMP(k) do { } while (0)
+#endif
+// Gradient replicas (ast_wgrad_rep): workgroups of pixel slice z add their tile into copy z % nrep of dw (copies nrep_stride
+// floats apart); whoever reads dw sums the copies (ast_weight_grads_flush_t).  Same-address f32 atomics serialise at ~155 ns
+// each wherever the address lives (tools/micro/l2atomic.hip: spreading the lines over channels or doing them at L2 level
+// changes nothing), so the flush of 85 workgroups per tile took 14 us of a 40 us launch (tools/wgrad_stamps.py); with 8
+// copies the chains are 11 deep.
+static thread_local int g_wg_nrep = 1;
+static thread_local long g_wg_rep_stride = 0;
 template <typename T> struct WgradCfg;
 template <> struct WgradCfg<bf16_t> { static constexpr int BKP = 64, PAD = 8; };    // elements
 template <> struct WgradCfg<float> { static constexpr int BKP = 32, PAD = 16; };
@@ -627,7 +640,7 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
                                                      float* __restrict__ dw, const ast_gather_t g,
                                                      const int P, const int pps, const unsigned dy_bytes,
                                                      const unsigned src_bytes, const float rcp_hw, const float rcp_w,
-                                                     const int gx, const int gy, const int gz) {
+                                                     const int gx, const int gy, const int gz, const int nrep, const long rep_stride) {
   constexpr int E = 16 / sizeof(T), ES = sizeof(T);
   constexpr int BKP = WgradCfg<T>::BKP, PAD = WgradCfg<T>::PAD;
   constexpr int BNW = NCT * 16;
@@ -656,6 +669,7 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
   const int chunk = gridDim.x >> 3;
   const int tix = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tix >= gx * gy * gz) return;
+  WG_STAMP(0); WG_STAMP(7);
   const int bx = tix / (gz * gy), bz = (tix / gy) % gz, by = tix % gy;
   const int cd0 = bx * BMW, col0 = by * BNW;
   const int ncols = g.ntaps * g.Cs;
@@ -727,6 +741,7 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
   const int nk_all = (p_end - p_begin + BKP - 1) / BKP;
   const int nk = (nk_all + PG - 1) / PG;                         // trips: every group runs all of them (workgroup-wide barriers);
   if (nk > 0) load_tile(p_begin + pg * BKP);                    // a group past the slice's end loads zeros (p >= p_end)
+  WG_STAMP(1);
   for (int kt = 0; kt < nk; ++kt) {
     store_tile();
     __syncthreads();
@@ -776,6 +791,7 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
     __syncthreads();                                             // operand reads done before the next store
   }
 
+  WG_STAMP(2);
   if constexpr (PG > 1) {                           // sum the groups' partial tiles through LDS (the staging is free now)
     f32x4* red = reinterpret_cast<f32x4*>(wl_all);
 #pragma unroll
@@ -800,6 +816,8 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
     }
     if (pg > 0) return;
   }
+  WG_STAMP(3);
+  dw += (size_t)(bz % nrep) * rep_stride;          // this pixel slice's gradient replica
   // D[row = cd (gq*4+r)][col = column li]
 #pragma unroll
   for (int j = 0; j < CTW; ++j) {
@@ -817,7 +835,16 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
         if (cd < g.Cd) unsafeAtomicAdd(dw + ((size_t)cd * g.wtaps + wtc) * g.Cs + c, acc[i][j][r]);
       }
   }
+#ifdef AST_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the atomics have been acknowledged
+#endif
+  WG_STAMP(4); WG_STAMP(6);
 }
+#ifdef AST_STAMPS
+extern "C" int ast_debug_read_wg_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ast_wg_stamps), (size_t)n * 8 * sizeof(unsigned long long));
+}
+#endif
 
 template <typename T, int BMW, int NCT, int PG>
 int launch_wgrad_pg(const void* dy, const void* src, float* dw, const ast_gather_t& g, int P, hipStream_t s) {
@@ -841,7 +868,7 @@ int launch_wgrad_pg(const void* dy, const void* src, float* dw, const ast_gather
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
   const int total = gx * gy * nsplit;
   hipLaunchKernelGGL((wgrad_kernel<T, BMW, NCT, PG>), dim3((total + 7) / 8 * 8), dim3(256 * PG), LDS, s, (const T*)dy, (const T*)src, dw, g, P, pps,
-                     dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm, gx, gy, nsplit);
+                     dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm, gx, gy, nsplit, g_wg_nrep, g_wg_rep_stride);
   AST_CHECK_LAUNCH();
   return 0;
 }
@@ -876,7 +903,7 @@ struct WHaloPlan { int PH, PW, dhmin, dwmin, tiles_h, tiles_w, ntiles, lds; };
 template <typename T, int BMW, int NCT, int PG>
 __global__ __launch_bounds__(256 * PG) void wgrad_halo_kernel(const T* __restrict__ dy, const T* __restrict__ src,
                                                           float* __restrict__ dw, const ast_gather_t g, const WHaloPlan hp,
-                                                          const unsigned dy_bytes, const unsigned src_bytes) {
+                                                          const unsigned dy_bytes, const unsigned src_bytes, const int nrep, const long rep_stride) {
   constexpr int E = 16 / sizeof(T), ES = sizeof(T);
   constexpr int MT = WH_TH * WH_TW;                 // 128 pixels per tile
   constexpr int PADY = sizeof(T) == 2 ? 8 : 16;
@@ -1068,6 +1095,7 @@ __global__ __launch_bounds__(256 * PG) void wgrad_halo_kernel(const T* __restric
     if (pg > 0) return;
   }
   // D[row = cd (gq*4+r)][col = column li]
+  dw += (size_t)(blockIdx.z % nrep) * rep_stride;      // this slice's gradient replica (see g_wg_nrep)
 #pragma unroll
   for (int j = 0; j < CTW; ++j) {
     const int ct = wave + 4 * j;
@@ -1126,7 +1154,7 @@ int launch_wgrad_halo_pg(const void* dy, const void* src, float* dw, const ast_g
   const unsigned dy_bytes = (unsigned)((size_t)g.N * g.Hm * g.Wm * g.Cd * sizeof(T));
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
   hipLaunchKernelGGL((wgrad_halo_kernel<T, BMW, NCT, PG>), dim3(gx, gy, gz), dim3(256 * PG), lds, s, (const T*)dy, (const T*)src, dw, g, hp,
-                     dy_bytes, src_bytes);
+                     dy_bytes, src_bytes, g_wg_nrep, g_wg_rep_stride);
   AST_CHECK_LAUNCH();
   return 0;
 }
@@ -1797,6 +1825,16 @@ extern "C" int ast_igemm_bn(const void* src, const void* wgt, const float* bias,
 extern "C" int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t* gp,
                          int dtype, int flags, float* ws, long ws_floats, void* stream) {
   return ast_igemm_bn(src, wgt, bias, dst, gp, dtype, flags & ~48, ws, ws_floats, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t* gp, int dtype, void* stream);
+extern "C" int ast_wgrad_rep(const void* dy, const void* src, float* dw, const ast_gather_t* gp, int dtype, int nrep, void* stream) {
+  if (nrep < 1 || nrep > 64 || !gp) AST_FAIL("ast_wgrad_rep: 1..64 replicas");
+  g_wg_nrep = nrep;
+  g_wg_rep_stride = (long)gp->Cd * gp->wtaps * gp->Cs;
+  const int rc = ast_wgrad(dy, src, dw, gp, dtype, stream);
+  g_wg_nrep = 1; g_wg_rep_stride = 0;
+  return rc;
 }
 
 extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t* gp, int dtype, void* stream) {

@@ -273,20 +273,25 @@ __device__ __forceinline__ void pack_tile_body(const ast_weight_desc_t& d, const
   tile_load_master<KKC>(d, d.w, tl.co0, tl.ci0, L, 1.f / d.sigma[0]);
   __syncthreads();
   if (dtype == AST_BF16) tile_store_packed<bf16_t, KKC>(d, tl.co0, tl.ci0, L); else tile_store_packed<float, KKC>(d, tl.co0, tl.ci0, L);
+  const int nrep = d.dwp_replicas > 1 ? d.dwp_replicas : 1;           // gradient replicas (ast_wgrad_rep): all of them start at zero
+  const size_t rstride = (size_t)d.Cop * KK * d.Cip;
   if (d.dwp && d.power_iter && KKC > 0 && tile_is_full(d, tl.co0, tl.ci0) && (d.Cip & 3) == 0 && (d.Cop & 3) == 0) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     for (int idx = threadIdx.x; idx < TL * KK * 8; idx += 256) {
       const int q = idx & 7, row = idx >> 3;
       const int out_l = row / KK, tap = row - out_l * KK;
       float* p = d.dwp_from_wb ? d.dwp + ((size_t)(tl.ci0 + out_l) * KK + tap) * d.Cop + tl.co0 : d.dwp + ((size_t)(tl.co0 + out_l) * KK + tap) * d.Cip + tl.ci0;
-      *reinterpret_cast<f32x4*>(p + q * 4) = z;
+      for (int r = 0; r < nrep; ++r) *reinterpret_cast<f32x4*>(p + r * rstride + q * 4) = z;
     }
   } else if (d.dwp && d.power_iter) {         // fresh gradient staging for this step (this tile's slice, both layouts cover it once)
     for (int idx = threadIdx.x; idx < TL * KK * TL; idx += 256) {
       const int in_l = idx & (TL - 1), row = idx >> 5;
       const int out_l = row / KK, tap = row - out_l * KK;
-      if (d.dwp_from_wb) { const int ci = tl.ci0 + out_l, co = tl.co0 + in_l; if (ci < d.Cip && co < d.Cop) d.dwp[((size_t)ci * KK + tap) * d.Cop + co] = 0.f; }
-      else { const int co = tl.co0 + out_l, ci = tl.ci0 + in_l; if (co < d.Cop && ci < d.Cip) d.dwp[((size_t)co * KK + tap) * d.Cip + ci] = 0.f; }
+      for (int r = 0; r < nrep; ++r) {
+        float* base = d.dwp + r * rstride;
+        if (d.dwp_from_wb) { const int ci = tl.ci0 + out_l, co = tl.co0 + in_l; if (ci < d.Cip && co < d.Cop) base[((size_t)ci * KK + tap) * d.Cop + co] = 0.f; }
+        else { const int co = tl.co0 + out_l, ci = tl.ci0 + in_l; if (co < d.Cop && ci < d.Cip) base[((size_t)co * KK + tap) * d.Cip + ci] = 0.f; }
+      }
     }
   }
 }
@@ -306,12 +311,22 @@ __global__ __launch_bounds__(256) void pack_tiles_kernel(const ast_weight_desc_t
 template <int KKC>
 __device__ __forceinline__ void tile_load_dwp(const ast_weight_desc_t& d, int co0, int ci0, float* __restrict__ G) {
   const int KK = KKC > 0 ? KKC : d.KK;
+  const int nrep = d.dwp_replicas > 1 ? d.dwp_replicas : 1;           // gradient replicas (ast_wgrad_rep) are summed here
+  const size_t rstride = (size_t)d.Cop * KK * d.Cip;
   if (KKC > 0 && tile_is_full(d, co0, ci0) && (d.Cip & 3) == 0 && (d.Cop & 3) == 0) {
     for (int idx = threadIdx.x; idx < TL * KK * 8; idx += 256) {
       const int q = idx & 7, row = idx >> 3;
       const int out_l = row / KK, tap = row - out_l * KK;
       const float* p = d.dwp_from_wb ? d.dwp + ((size_t)(ci0 + out_l) * KK + tap) * d.Cop + co0 : d.dwp + ((size_t)(co0 + out_l) * KK + tap) * d.Cip + ci0;
-      const f32x4 v4 = *reinterpret_cast<const f32x4*>(p + q * 4);
+      f32x4 v4 = *reinterpret_cast<const f32x4*>(p + q * 4);
+      if (nrep == 8) {                              // the configured count: seven independent loads in flight, fixed summation order
+        f32x4 t[7];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) t[r] = *reinterpret_cast<const f32x4*>(p + (r + 1) * rstride + q * 4);
+        v4 = ((v4 + t[0]) + (t[1] + t[2])) + ((t[3] + t[4]) + (t[5] + t[6]));
+      } else {
+        for (int r = 1; r < nrep; ++r) v4 += *reinterpret_cast<const f32x4*>(p + r * rstride + q * 4);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int in_l = q * 4 + e;
@@ -326,8 +341,20 @@ __device__ __forceinline__ void tile_load_dwp(const ast_weight_desc_t& d, int co
     const int out_l = row / KK, tap = row - out_l * KK;
     float v = 0.f;
     int co_l, ci_l;
-    if (d.dwp_from_wb) { ci_l = out_l; co_l = in_l; const int ci = ci0 + ci_l, co = co0 + co_l; if (ci < d.Ci && co < d.Co) v = d.dwp[((size_t)ci * KK + tap) * d.Cop + co]; }
-    else { co_l = out_l; ci_l = in_l; const int co = co0 + co_l, ci = ci0 + ci_l; if (co < d.Co && ci < d.Ci) v = d.dwp[((size_t)co * KK + tap) * d.Cip + ci]; }
+    bool ok;
+    size_t off;
+    if (d.dwp_from_wb) { ci_l = out_l; co_l = in_l; const int ci = ci0 + ci_l, co = co0 + co_l; ok = ci < d.Ci && co < d.Co; off = ((size_t)ci * KK + tap) * d.Cop + co; }
+    else { co_l = out_l; ci_l = in_l; const int co = co0 + co_l, ci = ci0 + ci_l; ok = co < d.Co && ci < d.Ci; off = ((size_t)co * KK + tap) * d.Cip + ci; }
+    if (ok) {
+      if (nrep == 8) {                              // eight independent loads in flight (a run-time loop serialised them: 100 us per tile)
+        float t[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t[r] = d.dwp[r * rstride + off];
+        v = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+      } else {
+        for (int r = 0; r < nrep; ++r) v += d.dwp[r * rstride + off];
+      }
+    }
     G[(tap * TL + co_l) * LP + ci_l] = v;
   }
 }

@@ -84,6 +84,10 @@ int ast_igemm_plan(const ast_gather_t* g, int dtype, int* out5);
  * Replaces: weight gradients of Conv2d / ConvTranspose2d / Linear. */
 int ast_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t* g,
               int dtype, void* stream);
+/* The same with the gradient spread over `nrep` copies of dw (copy r at dw + r * Cd*wtaps*Cs; the workgroups of pixel slice z
+ * use copy z % nrep): same-address f32 atomics serialise, and the reader (ast_weight_grads_flush_t with
+ * ast_weight_desc_t.dwp_replicas) sums the copies.  All copies must be zeroed by the caller. */
+int ast_wgrad_rep(const void* dy, const void* src, float* dw, const ast_gather_t* g, int dtype, int nrep, void* stream);
 
 /* Token-sized nn.Linear (M <= 64 rows, f32): y = act(x W^T + b), W row pitch ldw (W may be a row slice
  * of in_proj_weight or the transposed pack for the data gradient).  One wave per output column. */
@@ -138,7 +142,7 @@ typedef struct ast_weight_desc_t {
   float* grad;          /* gradient of `w` (same layout as w), accumulated by ast_weight_grads_flush_t */
   float* inner;         /* [1] scratch: <dWp, W/sigma> */
   int32_t dwp_from_wb;  /* 0: dwp is [Cop][KK][Cip]; 1: [Cip][KK][Cop] */
-  int32_t pad_;
+  int32_t dwp_replicas; /* dwp holds this many copies (0 = 1), Cop*KK*Cip floats apart, filled by ast_wgrad_rep; flush sums them */
 } ast_weight_desc_t;
 /* descs: DEVICE array of n descriptors, dtypes: DEVICE int[n] (packed dtype per weight), tiles: DEVICE array of
  * {int32 weight index, co0, ci0, pad} covering every 32x32 channel tile of every weight (padded extents).

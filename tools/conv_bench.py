@@ -23,10 +23,14 @@ for name in layers:
     y = torch.empty(N, Ho, Wo, Cd, device="cuda", dtype=dt)
     stats = torch.zeros(64 * Cd * 2, device="cuda")
     wsz = torch.zeros(N * Ho * Wo * Cd, device="cuda")
-    dy = torch.randn(N, Ho, Wo, Cd, device="cuda").to(dt); dw = torch.zeros(Cd, k * k, Cs, device="cuda")
+    rep = int(os.environ.get("WGRAD_REP", "1"))                 # gradient replicas (ast_wgrad_rep)
+    dy = torch.randn(N, Ho, Wo, Cd, device="cuda").to(dt); dw = torch.zeros(rep, Cd, k * k, Cs, device="cuda")
     def run():
         if wgrad:
-            check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(dw), g, dcode(dt), stream()))
+            if rep > 1:
+                check(lib().ast_wgrad_rep(ptr(dy), ptr(x), ptr(dw), g, dcode(dt), rep, stream()))
+            else:
+                check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(dw), g, dcode(dt), stream()))
         else:
             if os.environ.get("NOSTATS"):
                 check(lib().ast_igemm(ptr(x), ptr(w), None, ptr(y), g, dcode(dt), 4, ptr(wsz), wsz.numel(), stream()))

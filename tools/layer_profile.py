@@ -18,9 +18,9 @@ def ig(src, wgt, bias, dst, g, flags=0, stats=None, bn=None, per_image=False):
     e0.record(); orig_ig(src, wgt, bias, dst, g, flags, stats, bn, per_image); e1.record()
     M = g.N*g.Hm*g.Wm
     recs.append(("igemm " + ops._igemm_config(g, ops.dcode(src.dtype)) + (" f32" if src.dtype == torch.float32 else ""), M, g.Cd, g.ntaps*g.Cs, g.ntaps, ops._gemm_cost(g, src.element_size()), e0, e1))
-def wg(dy, src, dwp, g):
+def wg(dy, src, dwp, g, replicas=1):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); orig_wg(dy, src, dwp, g); e1.record()
+    e0.record(); orig_wg(dy, src, dwp, g, replicas); e1.record()
     M = g.N*g.Hm*g.Wm
     recs.append(("wgrad" + (" f32" if src.dtype == torch.float32 else ""), M, g.Cd, g.ntaps*g.Cs, g.ntaps, ops._gemm_cost(g, src.element_size(), True), e0, e1))
 ops._igemm, ops._wgrad = ig, wg
