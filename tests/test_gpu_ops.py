@@ -196,6 +196,27 @@ def test_conv2d_patch_kernel(dtype, cin, cout, k, stride, H, W, N, nf):
         assert rel_err(s1, ref) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,N", [(32, 32, 3, 1, 40, 61, 4), (8, 32, 3, 2, 64, 97, 4), (64, 64, 3, 1, 30, 50, 4), (32, 64, 1, 2, 40, 60, 2)])
+def test_wgrad_replicas_sum_to_the_gradient(dtype, cin, cout, k, stride, H, W, N):
+    """ast_wgrad_rep spreads the workgroups' atomic tile flushes over `nrep` zeroed copies of dw (pixel slice z -> copy z % nrep);
+    the copies must add up to what ast_wgrad accumulates into one (the weight bank's flush does that sum)."""
+    from ast_amd._lib import check, dcode, lib, ptr, stream
+    config.set_compute_dtype(dtype)
+    torch.manual_seed(4)
+    g, (Ho, Wo) = ops.gather_direct(N, H, W, cin, cout, k, stride, 1 if k == 3 else 0)
+    x = torch.randn(N, H, W, cin, device=DEV).to(dtype)
+    dy = torch.randn(N, Ho, Wo, cout, device=DEV).to(dtype)
+    one = torch.zeros(cout, k * k, cin, device=DEV)
+    check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(one), g, dcode(dtype), stream()), "ast_wgrad")
+    for nrep in (2, 8):
+        rep = torch.zeros(nrep, cout, k * k, cin, device=DEV)
+        check(lib().ast_wgrad_rep(ptr(dy), ptr(x), ptr(rep), g, dcode(dtype), nrep, stream()), "ast_wgrad_rep")
+        torch.cuda.synchronize()
+        assert rel_err(rep.sum(0), one) < 1e-5
+        assert float(rep[1:].abs().max()) > 0 or Ho * Wo * N < 512          # the work really was spread
+
+
 @pytest.mark.parametrize("R_out,R_in", [(2, 8), (16, 32), (64, 128), (3, 300)])
 def test_rowmix_fwd_bwd(R_out, R_in):
     """ast_rowmix (class prototypes / prototype gather / section means, style_encoder.py:243-253, losses.py:88,142) for
