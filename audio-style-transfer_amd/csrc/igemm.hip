@@ -630,7 +630,7 @@ __device__ unsigned long long ast_wg_stamps[4096 * 8];      // wgrad_kernel phas
 static thread_local int g_wg_nrep = 1;
 static thread_local long g_wg_rep_stride = 0;
 template <typename T> struct WgradCfg;
-template <> struct WgradCfg<bf16_t> { static constexpr int BKP = 64, PAD = 8; };    // elements
+template <> struct WgradCfg<bf16_t> { static constexpr int BKP = 64, PAD = 16; };   // elements: row pitch = 32 B x odd for rows that are multiples of 64 B (see SWZ)
 template <> struct WgradCfg<float> { static constexpr int BKP = 32, PAD = 16; };
 
 // PG pixel groups of 4 waves per workgroup, as in wgrad_halo_kernel: group pg takes every PG-th K tile of the workgroup's pixel
@@ -648,6 +648,7 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
   constexpr int CPX = BNW / E, CPY = BMW / E;       // 16-byte chunks per row
   constexpr int NXI = (CPX + TPR - 1) / TPR, NYI = (CPY + TPR - 1) / TPR;
   constexpr int PX = BNW + PAD, PY = BMW + PAD;     // LDS pitches (elements)
+  constexpr bool SWZ = sizeof(T) == 2 && (CPX % 2 == 0) && (CPY % 2 == 0);
   constexpr int RT = BMW / 16;                      // row (cd) tiles, all handled by every wave
   constexpr int CTW = (NCT + 3) / 4;                // column tiles per wave
   constexpr unsigned OOB = 0x80000000u;
@@ -719,15 +720,20 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
     }
   };
   auto store_tile = [&]() __attribute__((always_inline)) {
+    // bf16: 32-byte column segments are XOR-swizzled by bit 3 of the pixel row (SWZ): the transposed reads of a half-wave touch
+    // rows r..r+3 and r+8..r+11, which a pitch of 32 B x odd alone leaves on the same banks.  Measured: 128-channel layer
+    // 50.3 -> 48.4 us, 256-channel 47.1 -> 45.1, 512-channel 41.6 -> 39.0 (the pitch change alone: nothing); the
+    // SQ_LDS_BANK_CONFLICT count of the launch did not move (3.89 M, five per MFMA), so that counter is not what it measures
+    const int sw = SWZ ? ((lrow >> 3) & 1) << 1 : 0;             // in 16-byte chunks
 #pragma unroll
     for (int i = 0; i < NYI; ++i) {
       const int ch = tq + TPR * i;
-      if (ch < CPY) *reinterpret_cast<u32x4*>(Ys + lrow * PY + ch * E) = yreg[i];
+      if (ch < CPY) *reinterpret_cast<u32x4*>(Ys + lrow * PY + (ch ^ sw) * E) = yreg[i];
     }
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
       const int ch = tq + TPR * i;
-      if (ch < CPX) *reinterpret_cast<u32x4*>(Xs + lrow * PX + ch * E) = xreg[i];
+      if (ch < CPX) *reinterpret_cast<u32x4*>(Xs + lrow * PX + (ch ^ sw) * E) = xreg[i];
     }
   };
 
@@ -752,19 +758,20 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
 #pragma unroll
       for (int ks = 0; ks < BKP / 32; ++ks) {
         const int r_lo = ks * 32 + 8 * gq + q;
+        const int sx = SWZ ? (gq & 1) << 4 : 0;                 // rows r_lo and r_lo + 4 share bit 3 = gq & 1 (elements)
         bf16x8 af[RT];
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Ys + r_lo * PY + i * 16 + pcol));
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Ys + (r_lo + 4) * PY + i * 16 + pcol));
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Ys + r_lo * PY + ((i * 16) ^ sx) + pcol));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Ys + (r_lo + 4) * PY + ((i * 16) ^ sx) + pcol));
           af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
 #pragma unroll
         for (int j = 0; j < CTW; ++j) {
           const int ct = wave + 4 * j;                          // uniform per wave
           if (ct < NCT) {
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xs + r_lo * PX + ct * 16 + pcol));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xs + (r_lo + 4) * PX + ct * 16 + pcol));
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xs + r_lo * PX + ((ct * 16) ^ sx) + pcol));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xs + (r_lo + 4) * PX + ((ct * 16) ^ sx) + pcol));
             const bf16x8 bf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
             for (int i = 0; i < RT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
