@@ -177,6 +177,7 @@ class Trainer:
         self._force_coll = os.environ.get("AST_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
         self._dist = world > 1 or self._force_coll
         self._dist_in_graph = None                   # decided at the first graph step (probe)
+        self._replicas_checked = False
         self._glob = None
         self._stream_d = None
         self._graphs = {}
@@ -496,6 +497,8 @@ class Trainer:
             static_x.copy_(x)
         if not segmented:
             graphs[0].replay()
+            if self._dist and self.world > 1 and not self._replicas_checked:
+                self._check_replicas_after_first_replay()
         else:                                   # data parallel, three-graph form: the two flat-gradient all-reduces run between replays
             graphs[0].replay()
             if self._dist:
@@ -506,6 +509,26 @@ class Trainer:
             graphs[2].replay()
         self.losses = outs
         return outs
+
+    def _check_replicas_after_first_replay(self):
+        """Once, after the first replay with the collectives inside the graph: every rank must hold the same parameters
+        (identical replicas + the MEAN gradient = identical updates).  A captured all-reduce that silently did nothing
+        would leave them different; then the ranks resynchronise from rank 0 and continue in the three-graph form."""
+        self._replicas_checked = True
+        chk = torch.stack([self.G.flat_p.double().sum(), self.D.flat_p.double().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if bool(((hi - lo).abs() <= 1e-9 * (1.0 + hi.abs())).all()):
+            return
+        if self.rank == 0:
+            print("[ast_amd] replicas diverged after a step with the collectives inside the graph: resynchronising and "
+                  "falling back to the three-graph form", flush=True)
+        for grp in (self.G, self.D):
+            for t in (grp.flat_p, grp.m, grp.v, grp.step):
+                dist.broadcast(t, src=0)
+        self._dist_in_graph = False
+        self._graphs.clear()
 
     def sync_buffers(self):
         """Data parallel, default mode: every rank's BatchNorm running statistics follow its own shard.  Average them

@@ -89,3 +89,44 @@ def test_gather_rows_autograd_gloo_world2():
         assert torch.allclose(torch.tensor(grad), wsum[rows].expand(-1, 5))
         assert labels == [0, 0, 0, 0, 1, 1, 1, 1]
     assert parallel.global_row_order(8, 2) == [(0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (0, 3), (1, 2), (1, 3)]
+
+
+def _replica_check_worker(rank, world, port, q):
+    """Trainer._check_replicas_after_first_replay on stand-in optimiser groups (CPU tensors, gloo)."""
+    import types
+    from ast_amd.train import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def group(scale):
+        return types.SimpleNamespace(flat_p=torch.arange(100, dtype=torch.float32) * scale, m=torch.full((100,), float(rank)),
+                                     v=torch.full((100,), float(rank)), step=torch.tensor([3 + rank]))
+    out = []
+    for diverged in (False, True):
+        tr = types.SimpleNamespace(rank=rank, world=world, G=group(1.0 + (0.5 * rank if diverged else 0.0)), D=group(2.0),
+                                   _graphs={"k": 1}, _dist_in_graph=True, _replicas_checked=False)
+        Trainer._check_replicas_after_first_replay(tr)
+        out.append((tr._dist_in_graph, len(tr._graphs), tr.G.flat_p.tolist(), tr.G.m.tolist()[0], int(tr.G.step)))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_check_keeps_identical_ranks_and_resyncs_diverged_ones_gloo_world2():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replica_check_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = (torch.arange(100, dtype=torch.float32)).tolist()
+    for rank in (0, 1):
+        same, div = res[rank]
+        assert same[0] is True and same[1] == 1 and same[2] == base and same[3] == float(rank)      # untouched
+        assert div[0] is False and div[1] == 0 and div[2] == base and div[3] == 0.0 and div[4] == 3   # rank 0's state everywhere, graphs dropped
