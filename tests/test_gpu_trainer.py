@@ -166,7 +166,9 @@ def test_graph_replays_read_each_new_batch():
     assert abs(eager[2]["rec"] - eager[0]["rec"]) > 0.1 * abs(eager[0]["rec"])        # the batches do differ
     for i, (g, e) in enumerate(zip(graph, eager)):
         for k in e:
-            tol = 5e-3 if i > 0 else (2e-3 if k in ("adv_g", "total") else 2e-4)
+            # later steps sit behind optimiser updates whose first Adam step is sign-sensitive to summation-order noise (f32
+            # atomics; one run in ~15 exceeded 5e-3 on a later step), the first step only behind the forward pass
+            tol = 1.5e-2 if i > 0 else (4e-3 if k in ("adv_g", "total") else 5e-4)
             assert math.isclose(g[k], e[k], rel_tol=tol, abs_tol=1e-5), (i, k, g[k], e[k])
 
 
