@@ -37,7 +37,7 @@ def test_trainer_modes_agree():
             for k in r:
                 # f32-atomic summation order differs run to run and compounds over steps; adv_g / total sit behind the
                 # discriminator's sign-sensitive first Adam update (two identical eager runs differ by 3e-4 there)
-                tol = 5e-3 if i > 0 else (2e-3 if k in ("adv_g", "total") else 2e-4)
+                tol = 1.5e-2 if i > 0 else (4e-3 if k in ("adv_g", "total") else 5e-4)      # see test_graph_replays_read_each_new_batch
                 assert math.isclose(h[k], r[k], rel_tol=tol, abs_tol=1e-5), (mode, i, k, h[k], r[k])
         assert math.isclose(a, ref_abs, rel_tol=1e-6), (mode, a, ref_abs)
 
@@ -253,7 +253,7 @@ def test_set_frontend_per_batch_under_graph():
     assert abs(res[0][1]["rec"] - res[0][0]["rec"]) > 1e-3
     for i, (e, g) in enumerate(zip(*res)):
         for k in e:
-            tol = 5e-3 if i > 0 else (2e-3 if k in ("adv_g", "total") else 2e-4)
+            tol = 1.5e-2 if i > 0 else (4e-3 if k in ("adv_g", "total") else 5e-4)
             assert math.isclose(e[k], g[k], rel_tol=tol, abs_tol=1e-5), (i, k, e[k], g[k])
 
 
