@@ -866,7 +866,8 @@ int launch_wgrad_pg(const void* dy, const void* src, float* dw, const ast_gather
   }
   const int gx = (g.Cd + BMW - 1) / BMW, gy = (g.ntaps * g.Cs + NCT * 16 - 1) / (NCT * 16);
   const int tiles = gx * gy;
-  const int wg_target = P >= 1500000 ? 768 : 256;       // see launch_wgrad_halo
+  const char* wte = getenv("AST_WGRAD_WG_TARGET");
+  const int wg_target = wte ? atoi(wte) : (P >= 1500000 ? 768 : 256);       // see launch_wgrad_halo
   int nsplit = std::max(1, std::min((P + 4 * BKP - 1) / (4 * BKP), (wg_target + tiles - 1) / tiles));
   int pps = (P + nsplit - 1) / nsplit;
   pps = (pps + BKP - 1) / BKP * BKP;
