@@ -618,6 +618,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
 // ---------------------------------------------------------------------------
 #ifdef AST_STAMPS
 __device__ unsigned long long ast_wg_stamps[4096 * 8];      // wgrad_kernel phase stamps (tools/wgrad_stamps.py)
+__device__ long long ast_wg_phase[4096 * 4];                // K-loop sub-phases: load issue, reads + MFMA, second barrier, trips
 #define WG_STAMP(k) do { if (threadIdx.x == 0 && tix < 4096) ast_wg_stamps[tix * 8 + (k)] = (k) >= 6 ? wall_clock64() : __builtin_readcyclecounter(); } while (0)
 #else
 #define WG_STAMP(k) do { } while (0)
@@ -748,10 +749,20 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
   const int nk = (nk_all + PG - 1) / PG;                         // trips: every group runs all of them (workgroup-wide barriers);
   if (nk > 0) load_tile(p_begin + pg * BKP);                    // a group past the slice's end loads zeros (p >= p_end)
   WG_STAMP(1);
+#ifdef AST_STAMPS
+  long long ph[5] = {0, 0, 0, 0, 0};              // cycles of thread 0 in: LDS store (incl. the wait for the loads), barrier, load issue, reads + MFMA, barrier
+#define WG_PH(i) do { const long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tph; tph = t_; } while (0)
+  long long tph = __builtin_readcyclecounter();
+#else
+#define WG_PH(i) do { } while (0)
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     store_tile();
+    WG_PH(0);
     __syncthreads();
+    WG_PH(1);
     if (kt + 1 < nk) load_tile(p_begin + ((kt + 1) * PG + pg) * BKP);       // in flight while this tile is consumed
+    WG_PH(2);
     if constexpr (sizeof(T) == 2) {
       typedef __attribute__((address_space(3))) bf16x4 lds_b4;
       const int q = li >> 2, pcol = (li & 3) * 4;                // lane 4q+p supplies row q, columns 4p..4p+3 of its 16-lane group
@@ -795,8 +806,13 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
         }
       }
     }
+    WG_PH(3);
     __syncthreads();                                             // operand reads done before the next store
+    WG_PH(4);
   }
+#ifdef AST_STAMPS
+  if (threadIdx.x == 0 && tix < 4096) { ast_wg_stamps[tix * 8 + 5] = (unsigned long long)((ph[0] << 32) | (ph[1] & 0xffffffffll)); ast_wg_phase[tix * 4 + 0] = ph[2]; ast_wg_phase[tix * 4 + 1] = ph[3]; ast_wg_phase[tix * 4 + 2] = ph[4]; ast_wg_phase[tix * 4 + 3] = nk; }
+#endif
 
   WG_STAMP(2);
   if constexpr (PG > 1) {                           // sum the groups' partial tiles through LDS (the staging is free now)
@@ -850,6 +866,9 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
 #ifdef AST_STAMPS
 extern "C" int ast_debug_read_wg_stamps(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ast_wg_stamps), (size_t)n * 8 * sizeof(unsigned long long));
+}
+extern "C" int ast_debug_read_wg_phases(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ast_wg_phase), (size_t)n * 4 * sizeof(long long));
 }
 #endif
 

@@ -28,6 +28,13 @@ print(f"{name}: {len(a)} workgroups stamped")
 for i, nm in enumerate(["prologue (tap table, loader descriptors, first loads)", "K loop over the pixel slice", "pixel-group reduction through LDS", "atomic flush of the tile"]):
     d = a[:, i + 1] - a[:, i]
     print(f"  {nm:55s} median {np.median(d):8.0f}  p10 {np.percentile(d, 10):8.0f}  p90 {np.percentile(d, 90):8.0f} cycles")
+ph = (ctypes.c_longlong * (n * 4))()
+f2 = lib().ast_debug_read_wg_phases; f2.argtypes = [ctypes.c_void_p, ctypes.c_int]; f2.restype = ctypes.c_int
+assert f2(ph, n) == 0
+pa = np.frombuffer(ph, dtype=np.int64).reshape(n, 4)[:len(a)]
+trips = np.maximum(pa[:, 3], 1)
+sub = np.stack([a[:, 5] >> 32, a[:, 5] & 0xffffffff, pa[:, 0], pa[:, 1], pa[:, 2]], axis=1) / trips[:, None]
+print(f"  K loop per trip ({int(np.median(trips))} trips, thread 0 of pixel group 0): " + ", ".join(f"{nm} {np.median(sub[:, i]):.0f}" for i, nm in enumerate(["LDS store + wait for the loads", "barrier", "issue next loads", "LDS reads + MFMA", "barrier"])) + " cycles")
 life = a[:, 4] - a[:, 0]
 us = (a[:, 6] - a[:, 7]) / 100.0
 print(f"  workgroup lifetime median {np.median(life):.0f} cycles = {np.median(us):.2f} us (shader clock {np.median(life / us) / 1e3:.2f} GHz); last workgroup ends at {(a[:, 6].max() - a[:, 7].min()) / 100.0:.1f} us")
