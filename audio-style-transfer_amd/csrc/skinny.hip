@@ -15,17 +15,19 @@ namespace {
 // so each lane ends up with 4 consecutive n of one token row m -> one 16-byte store.  Lane (i = l&15, g = l>>4)
 // loads 16 B of row i at k = kb + 16 s + 4 g: the four MFMAs of a step contract k = 4 g + e over g (e = 0..3),
 // the same k permutation on both operands.
-template <int NS>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// NW = waves per workgroup that split K (4; 8 for K = 1024, the FFN's second linear and the data gradient of its first:
+// 16 dependent-free loads + 64 MFMAs per wave made those launches 8.9 us against 4.8 us for the K = 256 ones).
+template <int NS, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void skinny_gemm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int M, int N,
                                                            int K, int ldx, int ldw, int ldy, int relu,
                                                            const float* __restrict__ mul_mask, float* __restrict__ drop_mask,
                                                            float p, uint64_t seed, const int64_t* __restrict__ d_offset) {
-  __shared__ f32x4 part[4][64];
+  __shared__ f32x4 part[NW][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
-  constexpr int kslice = NS * 16;                     // k per wave (host: 4 * kslice >= K)
+  constexpr int kslice = NS * 16;                     // k per wave (host: NW * kslice >= K)
   const int kb = wave * kslice;
   const bool nv = n0 + i < N, mv = m0 + i < M;
   const float* wr = w + (size_t)(nv ? n0 + i : 0) * ldw;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
   if (wave != 0) return;
   f32x4 r = part[0][lane];
 #pragma unroll
-  for (int q = 1; q < 4; ++q) { const f32x4 t = part[q][lane]; r[0] += t[0]; r[1] += t[1]; r[2] += t[2]; r[3] += t[3]; }
+  for (int q = 1; q < NW; ++q) { const f32x4 t = part[q][lane]; r[0] += t[0]; r[1] += t[1]; r[2] += t[2]; r[3] += t[3]; }
   const int m = m0 + i, nb = n0 + 4 * g;              // D[row = 4 g + r (n)][col = i (m)]
   if (m >= M) return;
   // optional epilogues of the fused FFN: drop_mask != null draws the dropout mask here and stores the COMBINED
@@ -387,7 +389,10 @@ extern "C" int ast_skinny_gemm_ex(const float* x, const float* w, const float* b
   if (steps <= 2) AST_SK(2);
   else if (steps <= 4) AST_SK(4);
   else if (steps <= 8) AST_SK(8);
-  else if (steps <= 16) AST_SK(16);
+  else if (steps <= 16) {                             // eight waves, 8 steps each
+    hipLaunchKernelGGL((skinny_gemm_kernel<8, 8>), grid, dim3(512), 0, s, x, w, bias, y, M, N, K, K, ldw, ldy, relu, mul_mask, drop_mask, p,
+                       seed, d_offset);
+  }
   else AST_FAIL("ast_skinny_gemm: K=%d too large for the token path (<= 1024)", K);
 #undef AST_SK
   AST_CHECK_LAUNCH();
