@@ -166,7 +166,10 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, T* __restrict_
 }
 
 // ---- attention core for L <= 16 tokens: one wave per (batch, head), lane = feature
+// ML = the compile-time key-count bound (4, 8 or 16): every per-key array is indexed by a fully unrolled loop under a
+// `j < Lk` predicate, so it lives in registers (runtime-indexed arrays went to scratch memory).
 constexpr int MAXL = 16;
+template <int ML>
 __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                        float* __restrict__ o, float* __restrict__ probs, int H, int Lq, int Lk, int dh,
                                                        int ldq, int ldk, int ldo, int causal, const float* __restrict__ drop,
@@ -178,25 +181,32 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
   const float dkeep = 1.f / (1.f - pdrop);
   const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
   const float scale = rsqrtf((float)dh);
-  float kv[MAXL], vv[MAXL];
-  for (int j = 0; j < Lk; ++j) {
+  float kv[ML], vv[ML];
+#pragma unroll
+  for (int j = 0; j < ML; ++j) {
+    if (j >= Lk) continue;
     kv[j] = lane < dh ? k[((size_t)b * Lk + j) * ldk + h * dh + lane] : 0.f;
     vv[j] = lane < dh ? v[((size_t)b * Lk + j) * ldk + h * dh + lane] : 0.f;
   }
   for (int i = 0; i < Lq; ++i) {
     const float qi = lane < dh ? q[((size_t)b * Lq + i) * ldq + h * dh + lane] * scale : 0.f;
-    float s[MAXL];
+    float s[ML];
     float mx = -INFINITY;
-    for (int j = 0; j < Lk; ++j) {
+  #pragma unroll
+    for (int j = 0; j < ML; ++j) {
+      if (j >= Lk) continue;
       s[j] = wave_sum(qi * kv[j]);
       if (causal && j > i) s[j] = -INFINITY;
       mx = fmaxf(mx, s[j]);
     }
     float den = 0.f;
-    for (int j = 0; j < Lk; ++j) { s[j] = __expf(s[j] - mx); den += s[j]; }
+  #pragma unroll
+    for (int j = 0; j < ML; ++j) if (j < Lk) { s[j] = __expf(s[j] - mx); den += s[j]; }
     float acc = 0.f;
     const size_t pbase = (((size_t)b * H + h) * Lq + i) * Lk;
-    for (int j = 0; j < Lk; ++j) {
+  #pragma unroll
+    for (int j = 0; j < ML; ++j) {
+      if (j >= Lk) continue;
       const float p = s[j] / den;
       if (lane == 0) probs[pbase + j] = p;
       acc += (drop ? p * drop[pbase + j] : (pdrop > 0.f ? p * dropout_keep(dbase, pbase + j, pdrop, dkeep) : p)) * vv[j];
@@ -205,6 +215,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
   }
 }
 
+template <int ML>
 __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, const float* __restrict__ probs, float* __restrict__ dq,
                                                        float* __restrict__ dk, float* __restrict__ dv, int H, int Lq, int Lk, int dh, int ldq,
@@ -214,8 +225,10 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
   const float dkeep = 1.f / (1.f - pdrop);
   const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
   const float scale = rsqrtf((float)dh);
-  float kv[MAXL], vv[MAXL], dkv[MAXL], dvv[MAXL];
-  for (int j = 0; j < Lk; ++j) {
+  float kv[ML], vv[ML], dkv[ML], dvv[ML];
+#pragma unroll
+  for (int j = 0; j < ML; ++j) {
+    if (j >= Lk) continue;
     kv[j] = lane < dh ? k[((size_t)b * Lk + j) * ldk + h * dh + lane] : 0.f;
     vv[j] = lane < dh ? v[((size_t)b * Lk + j) * ldk + h * dh + lane] : 0.f;
     dkv[j] = 0.f; dvv[j] = 0.f;
@@ -224,9 +237,11 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
     const float qi = lane < dh ? q[((size_t)b * Lq + i) * ldq + h * dh + lane] : 0.f;
     const float doi = lane < dh ? dout[((size_t)b * Lq + i) * ldo + h * dh + lane] : 0.f;
     const size_t pbase = (((size_t)b * H + h) * Lq + i) * Lk;
-    float dp[MAXL], p[MAXL];
+    float dp[ML], p[ML];
     float dot = 0.f;
-    for (int j = 0; j < Lk; ++j) {
+  #pragma unroll
+    for (int j = 0; j < ML; ++j) {
+      if (j >= Lk) continue;
       p[j] = probs[pbase + j];
       const float m = drop ? drop[pbase + j] : (pdrop > 0.f ? dropout_keep(dbase, pbase + j, pdrop, dkeep) : 1.f);
       dvv[j] += p[j] * m * doi;
@@ -234,18 +249,23 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
       dot += dp[j] * p[j];
     }
     float dqi = 0.f;
-    for (int j = 0; j < Lk; ++j) {
+  #pragma unroll
+    for (int j = 0; j < ML; ++j) {
+      if (j >= Lk) continue;
       const float ds = p[j] * (dp[j] - dot) * scale;
       dqi += ds * kv[j];
       dkv[j] += ds * qi;
     }
     if (lane < dh) dq[((size_t)b * Lq + i) * ldq + h * dh + lane] = dqi;
   }
-  if (lane < dh)
-    for (int j = 0; j < Lk; ++j) {
+  if (lane < dh) {
+#pragma unroll
+    for (int j = 0; j < ML; ++j) {
+      if (j >= Lk) continue;
       dk[((size_t)b * Lk + j) * ldk + h * dh + lane] = dkv[j];
       dv[((size_t)b * Lk + j) * ldk + h * dh + lane] = dvv[j];
     }
+  }
 }
 
 template <typename T>
@@ -422,8 +442,11 @@ extern "C" int ast_attn_fwd_p(const float* q, const float* k, const float* v, fl
                               const int64_t* d_offset, void* stream) {
   if (!q || !k || !v || !o || !probs || p < 0.f || p >= 1.f) AST_FAIL("ast_attn_fwd: bad args");
   if (Lq < 1 || Lk < 1 || Lq > MAXL || Lk > MAXL || dh < 1 || dh > 64) AST_FAIL("ast_attn_fwd: needs 1<=L<=%d and dh<=64 (Lq=%d Lk=%d dh=%d)", MAXL, Lq, Lk, dh);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, q, k, v, o, probs, H, Lq, Lk, dh, ldq, ldk, ldo,
-                     causal, drop_mask, p, seed, d_offset);
+#define AST_ATTN_FWD(ML_)                                                                                                          \
+  hipLaunchKernelGGL(attn_fwd_kernel<ML_>, dim3(B * H), dim3(64), 0, (hipStream_t)stream, q, k, v, o, probs, H, Lq, Lk, dh, ldq, ldk, \
+                     ldo, causal, drop_mask, p, seed, d_offset)
+  if (Lk <= 4) AST_ATTN_FWD(4); else if (Lk <= 8) AST_ATTN_FWD(8); else AST_ATTN_FWD(16);
+#undef AST_ATTN_FWD
   AST_CHECK_LAUNCH();
   return 0;
 }
@@ -436,8 +459,11 @@ extern "C" int ast_attn_bwd_p(const float* dout, const float* q, const float* k,
                               float p, uint64_t seed, const int64_t* d_offset, void* stream) {
   if (!dout || !q || !k || !v || !probs || !dq || !dk || !dv || p < 0.f || p >= 1.f) AST_FAIL("ast_attn_bwd: bad args");
   if (Lq < 1 || Lk < 1 || Lq > MAXL || Lk > MAXL || dh < 1 || dh > 64) AST_FAIL("ast_attn_bwd: needs 1<=L<=%d and dh<=64", MAXL);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, dout, q, k, v, probs, dq, dk, dv, H, Lq, Lk, dh,
-                     ldq, ldk, ldo, drop_mask, p, seed, d_offset);
+#define AST_ATTN_BWD(ML_)                                                                                                           \
+  hipLaunchKernelGGL(attn_bwd_kernel<ML_>, dim3(B * H), dim3(64), 0, (hipStream_t)stream, dout, q, k, v, probs, dq, dk, dv, H, Lq, Lk, \
+                     dh, ldq, ldk, ldo, drop_mask, p, seed, d_offset)
+  if (Lk <= 4) AST_ATTN_BWD(4); else if (Lk <= 8) AST_ATTN_BWD(8); else AST_ATTN_BWD(16);
+#undef AST_ATTN_BWD
   AST_CHECK_LAUNCH();
   return 0;
 }
