@@ -27,6 +27,7 @@ from .losses import adversarial_loss, disentanglement_loss, infoNCE_loss, margin
 from .new_decoder import Decoder, compute_comprehensive_loss
 from .parallel import gather_rows, global_labels
 from .style_encoder import StyleEncoder, _module_bank, class_prototypes, initialize_weights
+from . import layers as layers_mod
 
 
 @dataclasses.dataclass
@@ -326,7 +327,8 @@ class Trainer:
                 g_adv = adv_term()
             total = total + wt(c.w_adv, g_adv)
             parts["adv_g"] = g_adv.detach()
-        total.backward()
+        with layers_mod.parallel_flush():     # the three generator banks' gradient flushes side by side
+            total.backward()
         parts["total"] = total.detach()
         return parts
 
@@ -365,6 +367,15 @@ class Trainer:
         decoder forward and the D-independent losses; the streams join before the generator's adversarial term, which
         needs the updated discriminator (same arithmetic and order of updates as _step_body)."""
         c = self.cfg
+        held = self._prepare_beside_frontend()
+        try:
+            return self._step_overlapped_held(x, labels_host)
+        finally:
+            for b in held:
+                b.hold = False
+
+    def _step_overlapped_held(self, x, labels_host):
+        c = self.cfg
         self._run_frontend(x)
         y, style_emb, class_emb, content_emb, _ = self._forward_backward(x, labels_host, defer_d=True)
         main = torch.cuda.current_stream()
@@ -389,6 +400,27 @@ class Trainer:
             self.last_grad_g = self.G.flat_g.clone()
         self.G.adam(c.lr_g, c.betas, c.eps, c.max_grad_norm)
         return self._parts
+
+    def _prepare_beside_frontend(self):
+        """Spectral-norm iteration + weight packing of the three generator banks (5 launches each, ~0.1 ms on the step's
+        longest chain: tools/graph_critical_path.py) depend on the weights only: they go to the branch streams BEFORE the
+        front end runs on the main stream, and the modules' own prepare() calls are held for this step."""
+        if not self.cfg.multi_stream or os.environ.get("AST_EARLY_PREPARE", "1") == "0":
+            return []
+        main = torch.cuda.current_stream()
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        held = []
+        for st, mod in zip(self._streams, (self.style, self.content, self.decoder)):
+            bank = _module_bank(mod)
+            if bank.hold:
+                continue
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                bank.prepare(True)
+            bank.hold = True
+            held.append(bank)
+        return held
 
     def _one_graph(self):
         """The step as ONE captured graph: a single GPU, or data parallel with the collectives inside the graph."""
@@ -584,9 +616,18 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if not segmented:
-            gph = torch.cuda.CUDAGraph()
+            dot = os.environ.get("AST_GRAPH_DOT")    # tools/graph_critical_path.py: the captured step's nodes and edges
+            gph = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
             with torch.cuda.graph(gph, **({"capture_error_mode": "thread_local"} if self._dist else {})):
                 outs = self._step_body(static_x, labels_host)
+            if dot:
+                import ctypes
+                hip = ctypes.CDLL("libamdhip64.so")
+                hip.hipGraphDebugDotPrint.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint]
+                rc = hip.hipGraphDebugDotPrint(ctypes.c_void_p(gph.raw_cuda_graph()), dot.encode(), 1)      # 1 = verbose
+                if rc != 0:
+                    raise RuntimeError(f"hipGraphDebugDotPrint failed ({rc})")
+                gph.instantiate()
             graphs = [gph]
         else:
             # three graphs over ONE memory pool: the autograd graph built while capturing segment A is walked

@@ -158,11 +158,17 @@ __device__ __forceinline__ void epi_pixel(const EpiCtx<T>& ec, const ast_gather_
 // sum|sumsq) values over the 16 lanes so that ONE atomic instruction per pair of channel tiles carries them all (an
 // atomic costs its issue slot whatever the number of active lanes: 4-lane atomics per value made this slower than the
 // separate pass).  cbase = first channel of the wave's channel tiles.
+// red != nullptr: the workgroup's FOUR waves hold the same channels (they split the pixels): their values are summed through
+// `red` (LDS, (TN+1)/2 * 256 floats, free at this point up to a barrier) and wave 0 alone issues the atomics.  Same-address
+// f32 atomics serialise, and a 0.7 M-pixel layer has 5 382 tiles: per-wave atomics put 336 adds behind each other on every
+// address of the 64-slot table, 1 345 on a per-image table.  Every thread of the workgroup must arrive.
 template <int TN>
 __device__ __forceinline__ void epi_flush(float* ws, const bool bstats, const int Cd, float (&st1)[TN][4], float (&st2)[TN][4], const int tix,
-                                          const int cbase, const int fr, const int fq) {
+                                          const int cbase, const int fr, const int fq, float* red = nullptr) {
   const int KS = bstats ? 3 : 2;                               // floats per channel in the slot table
   float* slot = ws + (size_t)(tix < 0 ? ~tix : (tix & 63)) * Cd * KS;      // tix < 0: ~tix is the slot itself (per-image tables)
+  constexpr int NP = (TN + 1) / 2;
+  float val[NP];
 #pragma unroll
   for (int i0 = 0; i0 < TN; i0 += 2) {
     // value q = ii*8 + r*2 + which (which: 0 = st1, 1 = st2) ends, summed over the 16 pixels, in lane fr = q
@@ -176,16 +182,29 @@ __device__ __forceinline__ void epi_flush(float* ws, const bool bstats, const in
         v[ii * 8 + r * 2] = i0 + ii < NT ? st1[it][r] : 0.f;
         v[ii * 8 + r * 2 + 1] = i0 + ii < NT ? st2[it][r] : 0.f;
       }
-    const float val = row16_transpose_sum(v, fr);
+    val[i0 >> 1] = row16_transpose_sum(v, fr);
+  }
+  if (red) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    __syncthreads();                                            // the other waves may still read the last operand tiles
+#pragma unroll
+    for (int p = 0; p < NP; ++p) red[p * 256 + tid] = val[p];
+    __syncthreads();
+    if (tid >= 64) return;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) val[p] = (red[p * 256 + lane] + red[p * 256 + 64 + lane]) + (red[p * 256 + 128 + lane] + red[p * 256 + 192 + lane]);
+  }
+#pragma unroll
+  for (int i0 = 0; i0 < TN; i0 += 2) {
     const int ii = fr >> 3, r = (fr >> 1) & 3, which = fr & 1;
     const int co = cbase + (i0 + ii) * 16 + fq * 4 + r;
-    if (i0 + ii < TN && co < Cd) unsafeAtomicAdd(slot + (size_t)co * KS + which, val);
+    if (i0 + ii < TN && co < Cd) unsafeAtomicAdd(slot + (size_t)co * KS + which, val[i0 >> 1]);
   }
 }
 template <typename T, int TN>
 __device__ __forceinline__ void epi_flush(const EpiCtx<T>& ec, const ast_gather_t& g, float (&st1)[TN][4], float (&st2)[TN][4], const int tix,
-                                          const int cbase, const int fr, const int fq) {
-  epi_flush<TN>(ec.ws, ec.bstats, g.Cd, st1, st2, tix, cbase, fr, fq);
+                                          const int cbase, const int fr, const int fq, float* red = nullptr) {
+  epi_flush<TN>(ec.ws, ec.bstats, g.Cd, st1, st2, tix, cbase, fr, fq, red);
 }
 
 // KCH = 16-byte chunks per row staged per barrier (4 or 8; 8 = two 64-byte sub-tiles).
@@ -466,7 +485,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ s
     for (int i = 0; i < TN; ++i) col[i] = acc[i][j];
     epi_pixel<T, TN>(ec, g, col, m, bn0 + wn * WTN + fq * 4, st1, st2);
   }
-  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, per_image ? ~img : tix, bn0 + wn * WTN, fr, fq);
+  // WN == 1: the four waves split the tile's pixels and share its channels -> one atomic per value per WORKGROUP
+  float* const red = (KG == 1 && WN == 1) ? reinterpret_cast<float*>(lds_all) : nullptr;
+  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, per_image ? ~img : tix, bn0 + wn * WTN, fr, fq, red);
 }
 
 // ---- narrow layers: operands straight from L1/L2 into MFMA fragments, no LDS ----------------------------------------
@@ -583,7 +604,8 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(const T* __restrict__
     load_pix(j + 2, xa, pa);
     if (j + 1 < jt) compute(j + 1, xb, pb);
   }
-  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, tix, bn0, fr, fq);
+  __shared__ float red[(TN + 1) / 2 * 256];                  // the four waves split the pixels: one atomic per value per workgroup
+  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, tix, bn0, fr, fq, red);
 }
 
 template <typename T>
@@ -1510,7 +1532,8 @@ __global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(cons
   else if (bstats) run(std::integral_constant<int, 2>{});
   else run(std::integral_constant<int, 0>{});
   PC_STAMP(4);
-  if (stats || bstats) epi_flush<TN>(ws, bstats, g.Cd, st1, st2, (flags & 64) ? ~n : tix, bn0, fr, fq);      // bit 6: per-image slots (tiles never straddle images)
+  if (stats || bstats) epi_flush<TN>(ws, bstats, g.Cd, st1, st2, (flags & 64) ? ~n : tix, bn0, fr, fq,
+                                       (flags & 64) ? reinterpret_cast<float*>(pl) : nullptr);   // per-image tables only: with 64 slots the per-wave atomics are as fast (and one barrier pair cheaper)      // bit 6: per-image slots (tiles never straddle images)
   PC_STAMP(5); PC_STAMP(6);
 }
 #ifdef AST_STAMPS

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time the forward GEMM of the encoder's stride-1 3x3 layers (and optionally their weight gradients) in isolation:
-tools/conv_bench.py [layers=b0c2,b1c2,b2c2,b3c2] [iters=30] [wgrad]   -- one line per layer: us, TFLOP/s."""
+tools/conv_bench.py [layers=b0c2,b1c2,b2c2,b3c2] [iters=30] [wgrad]   -- one line per layer: us, TFLOP/s.
+NOSTATS=1: plain stores; PERIMG=1: per-image statistics (flags 8|64); default: fused BatchNorm statistics (flags 8)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "audio-style-transfer_amd")); sys.path.insert(0, ROOT)
@@ -34,6 +35,8 @@ for name in layers:
         else:
             if os.environ.get("NOSTATS"):
                 check(lib().ast_igemm(ptr(x), ptr(w), None, ptr(y), g, dcode(dt), 4, ptr(wsz), wsz.numel(), stream()))
+            elif os.environ.get("PERIMG"):                       # per-image (InstanceNorm) sums: flags bit 6, [N][Cd][2] table
+                check(lib().ast_igemm(ptr(x), ptr(w), None, ptr(y), g, dcode(dt), 8 | 64, ptr(stats), stats.numel(), stream()))
             else:
                 check(lib().ast_igemm(ptr(x), ptr(w), None, ptr(y), g, dcode(dt), 8, ptr(stats), stats.numel(), stream()))
     for _ in range(3): run()
