@@ -181,6 +181,8 @@ class Trainer:
         self._replicas_checked = False
         self._glob = None
         self._stream_d = None
+        self._pre_zeroed = False
+        self._stream_fe = None
         self._graphs = {}
         self._streams = None
         self._y_emb = None
@@ -195,8 +197,11 @@ class Trainer:
     # ------------------------------------------------------------------ one eager step
     def _forward_backward(self, x, labels_host, defer_d=False):
         c = self.cfg
-        self.G.zero_grad()
-        self.D.zero_grad()
+        if self._pre_zeroed:                         # _prepare_beside_frontend cleared both gradient buffers on a branch stream
+            self._pre_zeroed = False
+        else:
+            self.G.zero_grad()
+            self.D.zero_grad()
         if ops._DropState.counter is None or ops._DropState.counter.device != self.device:
             ops._DropState.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         check(lib().ast_counter_incr(ptr(ops._DropState.counter), stream()), "ast_counter_incr")
@@ -371,6 +376,7 @@ class Trainer:
         try:
             return self._step_overlapped_held(x, labels_host)
         finally:
+            self._pre_zeroed = False
             for b in held:
                 b.hold = False
 
@@ -411,6 +417,12 @@ class Trainer:
         if self._streams is None:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         held = []
+        st0 = self._streams[0]
+        st0.wait_stream(main)
+        with torch.cuda.stream(st0):                 # gradients are first touched in the backward pass, after the branches join
+            self.G.zero_grad()
+            self.D.zero_grad()
+        self._pre_zeroed = True
         for st, mod in zip(self._streams, (self.style, self.content, self.decoder)):
             bank = _module_bank(mod)
             if bank.hold:
@@ -506,10 +518,23 @@ class Trainer:
             return
         from .utilityFunctions import stft_sections
         waves, mean, std = self._frontend
-        stft_sections(waves, mean, std, n_sections=x.shape[1], F_total=x.shape[-1], out=x)
+        side = None
         if self._frontend_cqt is not None:
             from .cqt import cqt_sections
-            cqt_sections(waves, x, *self._frontend_cqt)
+            if self.cfg.multi_stream and self._streams is not None and os.environ.get("AST_FRONTEND_FORK", "1") != "0":
+                # the CQT (five dependent decimations, then the octave kernel: ~0.1 ms of small launches) and the STFT write
+                # disjoint bins of x: side by side
+                if self._stream_fe is None:
+                    self._stream_fe = torch.cuda.Stream(device=self.device)
+                main, side = torch.cuda.current_stream(), self._stream_fe
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    cqt_sections(waves, x, *self._frontend_cqt)
+            else:
+                cqt_sections(waves, x, *self._frontend_cqt)
+        stft_sections(waves, mean, std, n_sections=x.shape[1], F_total=x.shape[-1], out=x)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
 
     def step(self, x: torch.Tensor, labels_host: torch.Tensor):
         """x: (B,S,2,287,597) f32 on the device; labels on the HOST (balanced [0]*B/2+[1]*B/2 as

@@ -74,6 +74,9 @@ for node_cost in (0.0, 1.6):
     print(f"\nper-node dispatch cost {node_cost} us: longest chain {best[end]:.0f} us over {len(chain)} nodes; all nodes {total:.0f} us "
           f"({total / best[end]:.2f}x the chain)")
     if node_cost: break
+    if "--nodes" in sys.argv:
+        for n in chain:
+            print(f"    {n:4d} {dur[n]:7.1f} us  {fam(nodes[n][0])} {nodes[n][1]}{'  FORK' if len(succ[n]) > 1 else ''}{'  JOIN' if len(pred[n]) > 1 else ''}")
     on = collections.defaultdict(lambda: [0, 0.0]); al = collections.defaultdict(lambda: [0, 0.0])
     for n in chain:
         f = fam(nodes[n][0]); on[f][0] += 1; on[f][1] += dur[n]
