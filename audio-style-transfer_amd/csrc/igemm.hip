@@ -1670,7 +1670,7 @@ IgemmPlan plan_igemm(const ast_gather_t& g, int M, int dtype) {
   // 684 tiles, loses)
   static const long kg_blocks = getenv("AST_IGEMM_KG_BLOCKS") ? atol(getenv("AST_IGEMM_KG_BLOCKS")) : 400;
   // K tiles of 64 elements per group and barrier (kch 8): 21.0 -> 19.0 us on average over the 25 such launches of a replayed
-  // step (tools/kg_ab.sh; back-to-back isolated launches had preferred 32)
+  // step (tools/knob_ab.sh; back-to-back isolated launches had preferred 32)
   static const int kg_kch = getenv("AST_IGEMM_KG_KCH") ? atoi(getenv("AST_IGEMM_KG_KCH")) : 8;
   if (p.bm == 64 && p.bn == 64 && blocks < kg_blocks && KT >= 16) { p.kgroups = 4; p.kch = kg_kch == 4 ? 4 : 8; }
   else if (blocks < 200 && KT >= 16 && (long)M * g.Cd <= (1L << 20)) p.nsplit = blocks < 120 ? 4 : 2;
