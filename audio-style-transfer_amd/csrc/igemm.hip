@@ -908,7 +908,9 @@ int launch_wgrad_pg(const void* dy, const void* src, float* dw, const ast_gather
   const int gx = (g.Cd + BMW - 1) / BMW, gy = (g.ntaps * g.Cs + NCT * 16 - 1) / (NCT * 16);
   const int tiles = gx * gy;
   const char* wte = getenv("AST_WGRAD_WG_TARGET");
-  const int wg_target = wte ? atoi(wte) : (P >= 1500000 ? 768 : 256);       // see launch_wgrad_halo
+  // see launch_wgrad_halo; the single-group 64 x 192 tiles (23 launches of a step) take 384: 29.5-29.8 -> 28.1-28.3 us on
+  // average in the replayed step (tools/knob_ab.sh; 320: 29.1, 448: 30.5), the two-group and the narrow ones do not (32.7 -> 43.3)
+  const int wg_target = wte ? atoi(wte) : (P >= 1500000 ? 768 : (PG == 1 && NCT >= 12 ? 384 : 256));
   int nsplit = std::max(1, std::min((P + 4 * BKP - 1) / (4 * BKP), (wg_target + tiles - 1) / tiles));
   int pps = (P + nsplit - 1) / nsplit;
   pps = (pps + BKP - 1) / BKP * BKP;
