@@ -512,7 +512,8 @@ __global__ __launch_bounds__(256) void add_drop_ln_bwd256_kernel(const float* __
 
 // workgroups per statistics pass: every workgroup ends with C*K same-address f32 atomics, so FEWER is faster up to the
 // point where the chip runs dry (A/B on the whole step: 8192 -> 8.9 ms, 4096 -> 8.35, 2048 -> 7.9, 1024 -> 7.5, 256 -> 7.55)
-int reduce_blocks() { static const int v = getenv("AST_REDUCE_BLOCKS") ? atoi(getenv("AST_REDUCE_BLOCKS")) : 1024; return v; }
+// (round 2, per-kernel time in the replayed step, tools/knob_ab.sh: 1024 -> 16.4-16.6 us, 512 -> 14.9, 384 -> 14.8, 256 -> 17.1)
+int reduce_blocks() { static const int v = getenv("AST_REDUCE_BLOCKS") ? atoi(getenv("AST_REDUCE_BLOCKS")) : 512; return v; }
 
 int elem_blocks() { static const int v = getenv("AST_ELEM_BLOCKS") ? atoi(getenv("AST_ELEM_BLOCKS")) : 2048; return v; }
 
