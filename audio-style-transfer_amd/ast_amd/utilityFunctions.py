@@ -34,7 +34,10 @@ def stft_sections(waves: torch.Tensor, mean=None, std=None, n_sections=None, F_t
         out = torch.zeros((Bc, n_sections, 2, WINDOW_SIZE, F_total), dtype=torch.float32, device=waves.device)
     check(lib().ast_stft_sections(ptr(waves.contiguous()), Bc, n, ptr(mean.contiguous()), ptr(std.contiguous()), ptr(out),
                                   n_sections, WINDOW_SIZE, step, F_total, stream()), "ast_stft_sections")
-    out.add_(0)        # version bump: the kernel wrote through the raw pointer (keeps version-keyed caches honest); no-op math
+    # version bump: the kernel wrote through the raw pointer (keeps version-keyed caches honest).  NOT `out.add_(0)`: that is a
+    # read-modify-write of ALL bins on this stream, and the CQT kernel fills bins >= 513 of the same tensor on another stream
+    # (train.Trainer._run_frontend) -- the no-op add wrote stale CQT bins back now and then (found by the mixed-length oracle test)
+    torch.autograd.graph.increment_version(out)
     return out
 
 
