@@ -521,9 +521,9 @@ class Trainer:
         side = None
         if self._frontend_cqt is not None:
             from .cqt import cqt_sections
-            if self.cfg.multi_stream and self._streams is not None and os.environ.get("AST_FRONTEND_FORK", "1") != "0":
+            if self.cfg.multi_stream and self._streams is not None and os.environ.get("AST_FRONTEND_FORK", "0") != "0":
                 # the CQT (five dependent decimations, then the octave kernel: ~0.1 ms of small launches) and the STFT write
-                # disjoint bins of x: side by side
+                # disjoint bins of x: side by side.  Opt-in (AST_FRONTEND_FORK=1): no measurable gain on the step
                 if self._stream_fe is None:
                     self._stream_fe = torch.cuda.Stream(device=self.device)
                 main, side = torch.cuda.current_stream(), self._stream_fe
