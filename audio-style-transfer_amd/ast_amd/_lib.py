@@ -101,6 +101,10 @@ _SIGS = {
     "ast_colsum_acc": ([vp, i64, i32, i32, vp, i32, vp], i32),
     "ast_sumsq": ([vp, i64, vp, vp], i32),
     "ast_adam": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp, f32, vp], i32),
+    "ast_adam_dev": ([vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, vp, vp], i32),
+    "ast_set_values": ([vp, C.POINTER(f32), i32, vp], i32),
+    "ast_weighted_sum": ([C.POINTER(vp), C.POINTER(i32), i32, vp, vp, vp], i32),
+    "ast_weighted_sum_bwd": ([vp, C.POINTER(i32), i32, vp, vp, vp], i32),
     "ast_counter_incr": ([vp, vp], i32),
     "ast_stft_sections": ([vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp], i32),
     "ast_cqt_octaves": ([vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, vp], i32),

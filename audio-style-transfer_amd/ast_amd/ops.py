@@ -1112,6 +1112,39 @@ def _scaled(grad_saved, gout):
     return y
 
 
+class WeightedSumFn(torch.autograd.Function):
+    """total = sum_i weights[widx_i] * term_i for scalar loss terms, the weights read from DEVICE memory at run time
+    (ast_weighted_sum): one launch forward, one backward, and a captured hipGraph follows a ramped loss weight without being
+    captured again.  widx_i < 0: weight 1."""
+
+    @staticmethod
+    def forward(ctx, weights, widx, *terms):
+        import ctypes as C
+        n = len(terms)
+        ts = [t.detach().reshape(1) for t in terms]
+        assert all(t.dtype == torch.float32 and t.is_cuda for t in ts) and len(widx) == n
+        out = torch.empty(1, dtype=torch.float32, device=weights.device)
+        parr = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        iarr = (C.c_int32 * n)(*[int(i) for i in widx])
+        check(lib().ast_weighted_sum(parr, iarr, n, ptr(weights), ptr(out), stream()), "ast_weighted_sum")
+        ctx.weights, ctx.widx, ctx.shapes = weights, tuple(int(i) for i in widx), [t.shape for t in terms]
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        n = len(ctx.widx)
+        grads = torch.empty(n, dtype=torch.float32, device=g.device)
+        iarr = (C.c_int32 * n)(*ctx.widx)
+        check(lib().ast_weighted_sum_bwd(ptr(g.contiguous().reshape(1)), iarr, n, ptr(ctx.weights), ptr(grads), stream()), "ast_weighted_sum_bwd")
+        return (None, None) + tuple(grads[i].view(shp) for i, shp in enumerate(ctx.shapes))
+
+
+def weighted_sum(weights, pairs):
+    """pairs: [(index into `weights` or -1, scalar tensor), ...] -> sum of weights[index] * tensor."""
+    return WeightedSumFn.apply(weights, tuple(i for i, _ in pairs), *[t for _, t in pairs])
+
+
 class ReconTotalFn(torch.autograd.Function):
     """compute_comprehensive_loss (new_decoder.py:348-420) in one pass: returns
     (total, raw sums[5]) and keeps d total / d out computed in the same pass."""

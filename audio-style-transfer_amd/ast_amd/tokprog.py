@@ -80,7 +80,8 @@ def check_status():
         st = int(status.item())
         if st != 0:
             status.zero_()
-            why = "a grid barrier timed out" if st == 1 else "the workgroups were not placed on one XCD (blockIdx % 8 != XCC_ID)"
+            why = {1: "a grid barrier timed out", 3: "fewer than G workgroups landed on the target XCD"}.get(
+                st, "the workgroups were not placed on one XCD (blockIdx % 8 != XCC_ID)")
             raise RuntimeError(f"ast_tok_program: {why} on {dev} (xcd {xcd}, status {st}); results are invalid")
 
 

@@ -30,6 +30,10 @@ from .style_encoder import StyleEncoder, _module_bank, class_prototypes, initial
 from . import layers as layers_mod
 
 
+# layout of Trainer.hyper (device-side step scalars): [lr, max_norm] pairs as ast_adam_dev reads them, then the loss weights
+H_LR_G, H_LR_D, H_W_REC, H_W_NCE, H_W_MARGIN, H_W_HSIC, H_W_ADV = 0, 2, 4, 5, 6, 7, 8
+
+
 @dataclasses.dataclass
 class TrainConfig:
     lr_g: float = 1e-4
@@ -119,12 +123,15 @@ class FlatGroup:
             return
         allreduce_mean_(self.flat_g, world, scale)
 
-    def adam(self, lr, betas, eps, max_norm):
-        self.gnorm_sq.zero_()
-        check(lib().ast_sumsq(ptr(self.flat_g), self.n, ptr(self.gnorm_sq), stream()), "ast_sumsq")
+    def adam(self, hyper, betas, eps, clip=True):
+        """hyper: DEVICE tensor [lr, max_norm], read by the kernel at run time (a replayed graph follows an LR schedule).
+        clip=False skips the gradient-norm pass altogether (structural: part of the graph key)."""
+        if clip:
+            self.gnorm_sq.zero_()
+            check(lib().ast_sumsq(ptr(self.flat_g), self.n, ptr(self.gnorm_sq), stream()), "ast_sumsq")
         check(lib().ast_counter_incr(ptr(self.step), stream()), "ast_counter_incr")
-        check(lib().ast_adam(ptr(self.flat_p), ptr(self.flat_g), ptr(self.m), ptr(self.v), self.n, lr, betas[0], betas[1], eps,
-                             0.0, ptr(self.step), ptr(self.gnorm_sq) if max_norm > 0 else None, max_norm, stream()), "ast_adam")
+        check(lib().ast_adam_dev(ptr(self.flat_p), ptr(self.flat_g), ptr(self.m), ptr(self.v), self.n, ptr(hyper), betas[0], betas[1], eps,
+                                 0.0, ptr(self.step), ptr(self.gnorm_sq) if clip else None, stream()), "ast_adam_dev")
 
 
 class Trainer:
@@ -162,6 +169,11 @@ class Trainer:
             m.to(self.device).train()
         self.G = FlatGroup([self.style, self.content, self.decoder], self.device)
         self.D = FlatGroup([self.disc], self.device)
+        # Step scalars live on the DEVICE (learning rates, clip norm, loss weights): the kernels read them at run time, so an
+        # LR schedule or a ramped adversarial weight (scheduler.step(), lambda_adv(t)) changes values between
+        # replays of ONE captured graph.  step() pushes cfg's current values before every step when they changed.
+        self.hyper = torch.zeros(16, dtype=torch.float32, device=self.device)
+        self._hyper_sent = None
         wire = os.environ.get("AST_GRAD_WIRE", self.cfg.grad_wire)
         if wire == "auto":
             nccl = dist.is_initialized() and dist.get_backend() == "nccl"
@@ -270,37 +282,31 @@ class Trainer:
     def _aux_losses(self, labels_host, style_emb, class_emb, content_emb):
         """The embedding losses that need neither the decoder nor the discriminator: margin, InfoNCE, HSIC."""
         c = self.cfg
-
-        def wt(w, t):                     # a weight of exactly 1.0 needs no multiply launch (forward and backward)
-            return t if w == 1.0 else w * t
         parts = {}
-        aux = wt(c.w_margin, margin_loss(class_emb))
+        terms = [(H_W_MARGIN, margin_loss(class_emb))]            # (index of the weight in self.hyper, loss term)
         style_b, labels_b, content_b = style_emb, labels_host, ops.mean_over_sections(content_emb)
         if self._matched:                    # batch-coupled terms on the gathered global batch
             style_b, labels_b = self._glob
             content_b = gather_rows(content_b, self.rank, self.world)
         if c.use_nce:
             nce = infoNCE_loss(style_b, labels_b)
-            aux = aux + wt(c.w_nce, nce)
+            terms.append((H_W_NCE, nce))
             parts["nce"] = nce.detach()
         if c.use_hsic:
             hs = disentanglement_loss(style_b, content_b)
-            aux = aux + wt(c.w_hsic, hs)
+            terms.append((H_W_HSIC, hs))
             parts["hsic"] = hs.detach()
-        return aux, parts
+        return terms, parts
 
     def _g_phase(self, x, y, labels_host, style_emb, class_emb, content_emb, before_adv=None, aux=None, side=None):
         c = self.cfg
-
-        def wt(w, t):
-            return t if w == 1.0 else w * t
         cls_rows = ops.class_rows(class_emb, labels_host)
         if self._simple:
             out = self.decoder(content_emb, cls_rows, y=y)
         else:
             out = self.decoder(content_emb, cls_rows, y=y, y_embeddings=self._y_emb)
         rec = self._rec_loss(out, y)
-        total = wt(c.w_rec, rec["total_loss"])
+        terms = [(H_W_REC, rec["total_loss"])]
         parts = {"rec": rec["total_loss"].detach()}
         def adv_term():
             bank_d = _module_bank(self.disc)
@@ -319,19 +325,22 @@ class Trainer:
                 aux = self._aux_losses(labels_host, style_emb, class_emb, content_emb)
                 if c.use_adv:
                     g_adv = adv_term()
-            aux[0].record_stream(torch.cuda.current_stream())
+            for _, t in aux[0]:
+                t.record_stream(torch.cuda.current_stream())
             if g_adv is not None:
                 g_adv.record_stream(torch.cuda.current_stream())
         if before_adv is not None:
             before_adv()                  # join the side stream
-        aux_total, aux_parts = aux if aux is not None else self._aux_losses(labels_host, style_emb, class_emb, content_emb)
-        total = total + aux_total
+        aux_terms, aux_parts = aux if aux is not None else self._aux_losses(labels_host, style_emb, class_emb, content_emb)
+        terms += aux_terms
         parts.update(aux_parts)
         if c.use_adv:
             if g_adv is None:
                 g_adv = adv_term()
-            total = total + wt(c.w_adv, g_adv)
+            terms.append((H_W_ADV, g_adv))
             parts["adv_g"] = g_adv.detach()
+        # total = w_rec rec + w_margin margin + w_nce nce + w_hsic hsic + w_adv adv_g, weights read from the device: one launch
+        total = ops.weighted_sum(self.hyper, terms)
         with layers_mod.parallel_flush():     # the three generator banks' gradient flushes side by side
             total.backward()
         parts["total"] = total.detach()
@@ -353,11 +362,11 @@ class Trainer:
             sd = self._stream_d
             sd.wait_stream(main)
             with torch.cuda.stream(sd):
-                self.D.adam(c.lr_d, c.betas, c.eps, c.max_grad_norm)
+                self.D.adam(self.hyper[H_LR_D:H_LR_D + 2], c.betas, c.eps, c.max_grad_norm > 0)
                 self.D.zero_grad()
             self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb, before_adv=lambda: main.wait_stream(sd), side=sd)
         else:
-            self.D.adam(c.lr_d, c.betas, c.eps, c.max_grad_norm)
+            self.D.adam(self.hyper[H_LR_D:H_LR_D + 2], c.betas, c.eps, c.max_grad_norm > 0)
             self.D.zero_grad()
             self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb)
         self._parts["adv_d"] = d_loss.detach()
@@ -365,7 +374,7 @@ class Trainer:
 
     def _seg_c(self, x, labels_host):
         c = self.cfg
-        self.G.adam(c.lr_g, c.betas, c.eps, c.max_grad_norm)
+        self.G.adam(self.hyper[H_LR_G:H_LR_G + 2], c.betas, c.eps, c.max_grad_norm > 0)
 
     def _step_overlapped(self, x, labels_host):
         """One GPU, one graph: the discriminator phase (D forward/backward + D's Adam) runs on its own stream beside the
@@ -393,7 +402,7 @@ class Trainer:
             d_loss = self._d_phase(style_emb, class_emb, content_emb, labels_host)
             if self._dist:
                 self.D.all_reduce(self.world, force=self._force_coll)
-            self.D.adam(c.lr_d, c.betas, c.eps, c.max_grad_norm)
+            self.D.adam(self.hyper[H_LR_D:H_LR_D + 2], c.betas, c.eps, c.max_grad_norm > 0)
             self.D.zero_grad()
         d_loss.record_stream(main)
         # margin / InfoNCE / HSIC go to the side stream too, but are CREATED after the decoder's nodes (inside _g_phase):
@@ -404,7 +413,7 @@ class Trainer:
             self.G.all_reduce(self.world, self._wire_dtype, force=self._force_coll)
         if c.keep_grads:
             self.last_grad_g = self.G.flat_g.clone()
-        self.G.adam(c.lr_g, c.betas, c.eps, c.max_grad_norm)
+        self.G.adam(self.hyper[H_LR_G:H_LR_G + 2], c.betas, c.eps, c.max_grad_norm > 0)
         return self._parts
 
     def _prepare_beside_frontend(self):
@@ -540,6 +549,7 @@ class Trainer:
         """x: (B,S,2,287,597) f32 on the device; labels on the HOST (balanced [0]*B/2+[1]*B/2 as
         dataloader.py:143-146 builds them).  Returns a dict of detached device scalars."""
         assert not labels_host.is_cuda, "pass labels on the host: avoids a device sync per step"
+        self._sync_hyper()
         if self._dist and self._dist_in_graph is None:
             self._dist_in_graph = False if self._matched else self._probe_collective_capture()
         if not self.cfg.use_graph:
@@ -549,6 +559,7 @@ class Trainer:
         key = self._graph_key(x, labels_host, segmented)
         if key not in self._graphs:
             self._capture(key, x, labels_host, segmented)
+            self._check_tok_programs(after_capture=True)
         graphs, static_x, outs = self._graphs[key]
         if static_x.data_ptr() != x.data_ptr():
             static_x.copy_(x)
@@ -565,7 +576,40 @@ class Trainer:
                 self.G.all_reduce(self.world, self._wire_dtype, force=self._force_coll)
             graphs[2].replay()
         self.losses = outs
+        self._check_tok_programs()
         return outs
+
+    def _sync_hyper(self):
+        """Push cfg's current step scalars to the device when they differ from what is there (one tiny launch whose values
+        travel as kernel arguments: stream-ordered behind the previous step, nothing for the host to wait for)."""
+        import ctypes
+        c = self.cfg
+        vals = [0.0] * 9
+        vals[H_LR_G], vals[H_LR_G + 1], vals[H_LR_D], vals[H_LR_D + 1] = c.lr_g, c.max_grad_norm, c.lr_d, c.max_grad_norm
+        vals[H_W_REC], vals[H_W_NCE], vals[H_W_MARGIN], vals[H_W_HSIC], vals[H_W_ADV] = c.w_rec, c.w_nce, c.w_margin, c.w_hsic, c.w_adv
+        vals = tuple(float(v) for v in vals)
+        if vals == self._hyper_sent:
+            return
+        arr = (ctypes.c_float * len(vals))(*vals)
+        check(lib().ast_set_values(ptr(self.hyper), arr, len(vals), stream()), "ast_set_values")
+        self._hyper_sent = vals
+
+    def _check_tok_programs(self, after_capture=False):
+        """Persistent token programs (AST_TOK_PROGRAMS=2, opt-in) depend on G workgroups landing on one XCD; a launch that did
+        not get them reports it in a device status word.  Checked after every capture's warm-up steps and every 256 steps:
+        on failure the trainer falls back to one launch per op (mode 1) and captures again."""
+        if config.tok_programs != 2:
+            return
+        self._tok_checked = getattr(self, "_tok_checked", 0) + 1
+        if not after_capture and self._tok_checked % 256:
+            return
+        from . import tokprog
+        try:
+            tokprog.check_status()
+        except RuntimeError as e:
+            print(f"[ast_amd] {e}; falling back to per-op token launches (AST_TOK_PROGRAMS=1)", flush=True)
+            config.tok_programs = 1
+            self._graphs.clear()
 
     def _check_replicas_after_first_replay(self):
         """Once, after the first replay with the collectives inside the graph: every rank must hold the same parameters
@@ -608,14 +652,14 @@ class Trainer:
             save_checkpoint(path, self.content, self.style, self.decoder, self.disc, **extra)
 
     def _graph_key(self, x, labels_host, segmented):
-        """Everything a captured step bakes in: shapes, labels (host-side class layout), dtype, curriculum gates, the
-        optimiser / clipping / loss-weight scalars (kernel arguments) and the front-end buffer addresses.  Changing any
-        of them between steps (an LR schedule, the curriculum, attaching a front end) captures a new graph instead of
-        silently replaying the old values."""
+        """Everything a captured step bakes in: shapes, labels (host-side class layout), dtype, curriculum gates, Adam's
+        betas / eps (kernel arguments), whether the gradient norm is clipped at all, and the front-end buffer addresses.
+        Changing any of them between steps captures a new graph instead of silently replaying the old values.  The
+        learning rates, the clip norm and the loss weights are NOT in the key: the kernels read them from self.hyper."""
         c = self.cfg
         fe = tuple(t.data_ptr() for t in (self._frontend or ())) + tuple(t.data_ptr() for t in (self._frontend_cqt or ()))
         return (tuple(x.shape), tuple(labels_host.tolist()), config.compute_dtype, c.use_nce, c.use_hsic, c.use_adv, segmented,
-                c.lr_g, c.lr_d, tuple(c.betas), c.eps, c.max_grad_norm, c.w_rec, c.w_nce, c.w_margin, c.w_hsic, c.w_adv, fe)
+                tuple(c.betas), c.eps, c.max_grad_norm > 0, fe)
 
     def _mutable_state(self):
         ts = [self.G.flat_p, self.G.m, self.G.v, self.G.step, self.D.flat_p, self.D.m, self.D.v, self.D.step]

@@ -1852,8 +1852,18 @@ extern "C" int ast_igemm_bn(const void* src, const void* wgt, const float* bias,
 #undef AST_PC
     }
   }
+  // argument checks of the gathered and direct kernels (the patch kernel's are above): a null or short workspace here is a
+  // write through a bad device pointer -- a GPU fault, not an error code
+  if (p.nsplit > 1) {
+    if (flags & (8 | 16)) AST_FAIL("ast_igemm: fused statistics (flags 8 / 16) are not available for a split-K plan (ast_igemm_ws_floats > 0)");
+    if (!ws || ws_floats < (long)M * g.Cd) AST_FAIL("ast_igemm: this plan splits K and needs a workspace of %ld floats (ast_igemm_ws_floats), got %ld", (long)M * g.Cd, ws ? ws_floats : 0L);
+  }
+  if ((flags & 16) && ((flags & 11) || !ws || ws_floats < 64L * g.Cd * 3 || !bn_x || !bn_scale || !bn_shift))
+    AST_FAIL("ast_igemm: fused BatchNorm-backward sums need plain stores, a zeroed [64][Cd][3] table and the layer's x / scale / shift");
+  if ((flags & 8) && !(flags & 64) && ((flags & 3) || !ws || ws_floats < 64L * g.Cd * 2))
+    AST_FAIL("ast_igemm: fused channel statistics need plain stores and a zeroed [64][Cd][2] table");
   if (flags & 64) {
-    if (!(flags & 8) || p.nsplit > 1 || direct_ok(g, p, dtype)) AST_FAIL("ast_igemm: per-image statistics (flag 64) need flag 8 and the gathered kernel (ast_igemm_plan: kch > 0, no split)");
+    if (!(flags & 8) || (flags & 3) || p.nsplit > 1 || direct_ok(g, p, dtype)) AST_FAIL("ast_igemm: per-image statistics (flag 64) need flag 8, plain stores and the gathered kernel (ast_igemm_plan: kch > 0, no split)");
     if (!ws || ws_floats < (long)g.N * g.Cd * 2) AST_FAIL("ast_igemm: per-image statistics need a zeroed [N][Cd][2] table");
   }
   if (direct_ok(g, p, dtype)) { AST_DISPATCH_T(dtype, { return dispatch_direct<T>(src, wgt, bias, dst, g, M, flags, ws, p, s); }); }

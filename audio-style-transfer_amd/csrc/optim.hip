@@ -32,11 +32,13 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
-                                                    const int64_t* __restrict__ d_step, const float* __restrict__ gnorm_sq, float max_norm) {
+                                                    const int64_t* __restrict__ d_step, const float* __restrict__ gnorm_sq, float max_norm,
+                                                    const float* __restrict__ d_hyper) {
+  if (d_hyper) { lr = d_hyper[0]; max_norm = d_hyper[1]; }         // [lr, max_norm] read at run time: a replayed graph follows a schedule
   const float step = (float)(*d_step);
   const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
   float clip = 1.f;
-  if (gnorm_sq) clip = fminf(1.f, max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f));
+  if (gnorm_sq && max_norm > 0.f) clip = fminf(1.f, max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f));
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float gi = g[i] * clip;
     if (wd != 0.f) gi += wd * p[i];
@@ -47,7 +49,58 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 __global__ void counter_incr_kernel(int64_t* c) { if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += 1; }
+
+// ---- step scalars that live on the device (LR schedule, clip norm, ramped loss weights under hipGraph replay) -------------
+struct HostVals { float v[AST_MAX_STEP_SCALARS]; };
+__global__ void set_values_kernel(float* __restrict__ dst, const HostVals hv, const int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = hv.v[threadIdx.x];
+}
+struct WsumArgs { const float* term[AST_MAX_STEP_SCALARS]; int widx[AST_MAX_STEP_SCALARS]; int n; };
+// out[0] = sum_i w[widx_i] * term_i[0]   (terms added in argument order: bit-reproducible)
+__global__ void weighted_sum_kernel(const WsumArgs a, const float* __restrict__ w, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < a.n; ++i) s += (a.widx[i] >= 0 ? w[a.widx[i]] : 1.f) * a.term[i][0];
+  out[0] = s;
+}
+// grads[i] = g[0] * w[widx_i]
+__global__ void weighted_sum_bwd_kernel(const float* __restrict__ g, const WsumArgs a, const float* __restrict__ w, float* __restrict__ grads) {
+  if ((int)threadIdx.x < a.n) grads[threadIdx.x] = g[0] * (a.widx[threadIdx.x] >= 0 ? w[a.widx[threadIdx.x]] : 1.f);
+}
 }  // namespace
+
+extern "C" int ast_set_values(float* dst, const float* host_vals, int n, void* stream) {
+  if (!dst || !host_vals || n < 1 || n > AST_MAX_STEP_SCALARS) AST_FAIL("ast_set_values: 1..%d values", AST_MAX_STEP_SCALARS);
+  HostVals hv;
+  for (int i = 0; i < AST_MAX_STEP_SCALARS; ++i) hv.v[i] = i < n ? host_vals[i] : 0.f;
+  hipLaunchKernelGGL(set_values_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, hv, n);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int ast_weighted_sum(const float* const* terms, const int* widx, int n, const float* weights, float* out, void* stream) {
+  if (!terms || !widx || !weights || !out || n < 1 || n > AST_MAX_STEP_SCALARS) AST_FAIL("ast_weighted_sum: 1..%d terms", AST_MAX_STEP_SCALARS);
+  WsumArgs a;
+  a.n = n;
+  for (int i = 0; i < AST_MAX_STEP_SCALARS; ++i) {
+    a.term[i] = i < n ? terms[i] : nullptr; a.widx[i] = i < n ? widx[i] : -1;
+    if (i < n && (!terms[i] || widx[i] >= AST_MAX_STEP_SCALARS)) AST_FAIL("ast_weighted_sum: term %d: null pointer or weight index out of range", i);
+  }
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, weights, out);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int ast_weighted_sum_bwd(const float* g, const int* widx, int n, const float* weights, float* grads, void* stream) {
+  if (!g || !widx || !weights || !grads || n < 1 || n > AST_MAX_STEP_SCALARS) AST_FAIL("ast_weighted_sum_bwd: 1..%d terms", AST_MAX_STEP_SCALARS);
+  WsumArgs a;
+  a.n = n;
+  for (int i = 0; i < AST_MAX_STEP_SCALARS; ++i) {
+    a.term[i] = nullptr; a.widx[i] = i < n ? widx[i] : -1;
+    if (i < n && widx[i] >= AST_MAX_STEP_SCALARS) AST_FAIL("ast_weighted_sum_bwd: weight index out of range");
+  }
+  hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g, a, weights, grads);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int ast_sumsq(const float* x, int64_t n, float* out, void* stream) {
   if (!x || !out || n < 0) AST_FAIL("ast_sumsq: bad args");
@@ -67,7 +120,17 @@ extern "C" int ast_adam(float* p, const float* g, float* m, float* v, int64_t n,
   if (n == 0) return 0;
   const int grid = (int)std::min<size_t>(((size_t)n + 255) / 256, 4096);
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, lr, b1, b2, eps, wd, d_step,
-                     gnorm_sq, max_norm);
+                     gnorm_sq, max_norm, (const float*)nullptr);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int ast_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* d_hyper, float b1, float b2, float eps, float wd,
+                            const int64_t* d_step, const float* gnorm_sq, void* stream) {
+  if (!p || !g || !m || !v || !d_step || !d_hyper || n < 0) AST_FAIL("ast_adam_dev: bad args");
+  if (n == 0) return 0;
+  const int grid = (int)std::min<size_t>(((size_t)n + 255) / 256, 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, 0.f, b1, b2, eps, wd, d_step,
+                     gnorm_sq, 0.f, d_hyper);
   AST_CHECK_LAUNCH();
   return 0;
 }

@@ -512,14 +512,22 @@ __global__ __launch_bounds__(256) void tok_program_kernel(const TokProgram prog,
   // was wrong under graph replay, and an 8 G grid did not always put G on the target), so the grid is 16 G and the surplus
   // exits.  `sync` (agent-scope atomics throughout): [0] barrier arrivals, [1] finished participants, and in another cache
   // line [16] exited workgroups, [17] tickets.
-  // The last participant zeroes the first group, the last workgroup of the grid the second: the next launch (a replay of
-  // the same graph node) starts from zero.
+  // The last workgroup of the grid to exit zeroes all of them: the next launch (a replay of the same graph node) starts
+  // from zero whatever happened in this one.
   extern __shared__ __attribute__((aligned(16))) unsigned char tok_lds[];
   const int G = prog.G;
   auto leave = [&]() __attribute__((always_inline)) {
     if (threadIdx.x == 0) {
       const unsigned gone = __hip_atomic_fetch_add(sync + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (gone == gridDim.x - 1) {
+        // The LAST workgroup of the grid to exit resets every counter unconditionally.  (The barrier counters used to be
+        // zeroed only when exactly G participants finished: with fewer than G workgroups landing on the target XCD the
+        // barriers time out, the finished count never reaches G, and the stale arrivals would let every later launch or
+        // graph replay pass its barriers early -- silent data races.)  Fewer than G tickets: status 3.
+        if (__hip_atomic_load(sync + 17, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G)
+          __hip_atomic_store(status, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(sync + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(sync + 17, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -541,11 +549,7 @@ __global__ __launch_bounds__(256) void tok_program_kernel(const TokProgram prog,
     TOK_STAMP(2);
   }
   __syncthreads();
-  if (threadIdx.x == 0 && __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)G - 1) {
-    __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // every participant has left its last barrier
-    __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  leave();
+  leave();                                        // (the last workgroup of the grid to exit zeroes all counters)
 }
 
 }  // namespace

@@ -303,6 +303,21 @@ int ast_sumsq(const float* x, int64_t n, float* out /* accumulates */, void* str
 int ast_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
              float eps, float wd, const int64_t* d_step, const float* gnorm_sq, float max_norm, void* stream);
 
+/* Step scalars on the device, so that ONE captured hipGraph follows a learning-rate schedule, a ramped adversarial weight or
+ * a changed clip norm (the reconstructed train2 step: `scheduler.step()` and lambda_adv(t); README.md:144-150).
+ * ast_adam_dev: as ast_adam, with [lr, max_norm] read from device memory at run time (max_norm <= 0: no clipping).
+ * ast_set_values: dst[i] = host_vals[i], i < n <= AST_MAX_STEP_SCALARS -- the values travel as kernel arguments (stream-ordered,
+ * no pinned staging buffer to race with).
+ * ast_weighted_sum: out[0] = sum_i weights[widx[i]] * terms[i][0] (widx[i] < 0: weight 1), terms added in order -- the total loss
+ * `w_rec * rec + w_nce * nce + ...` of the train step in one launch; _bwd: grads[i] = g[0] * weights[widx[i]].
+ * `terms` / `widx` are HOST arrays of n <= AST_MAX_STEP_SCALARS entries (device pointers / indices into `weights`). */
+#define AST_MAX_STEP_SCALARS 16
+int ast_adam_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* d_hyper /* [lr, max_norm] */, float b1, float b2,
+                 float eps, float wd, const int64_t* d_step, const float* gnorm_sq, void* stream);
+int ast_set_values(float* dst, const float* host_vals, int n, void* stream);
+int ast_weighted_sum(const float* const* terms, const int* widx, int n, const float* weights, float* out, void* stream);
+int ast_weighted_sum_bwd(const float* g, const int* widx, int n, const float* weights, float* grads, void* stream);
+
 /* ---- STFT front-end (utilityFunctions.py:12-37 + dataloader.py:9-13 + utilityFunctions.py:240-263) */
 /* wave (Bc, nsamp) f32 -> x (Bc, S, 2, 287, F_total) f32: frames of a 1024-point Hann STFT (hop 256,
  * reflect padded), z-scored with mean/std (2,513), cut into S sections of 287 frames (step 191), written

@@ -38,7 +38,7 @@ class Cfg:
     dropout probability used where the reference has nn.Dropout(0.1) -- parity
     runs use 0.0 because torch's RNG stream is not part of the contract."""
 
-    def __init__(self, training: bool = True, p_drop: float = 0.0, act_dtype=None):
+    def __init__(self, training: bool = True, p_drop: float = 0.0, act_dtype=None, act_stages=None):
         self.training = training
         self.p_drop = p_drop
         # None: the fp32 reference arithmetic.  torch.bfloat16: additionally ROUND every image activation (and its
@@ -47,6 +47,20 @@ class Cfg:
         # weight gradients stay f32) -- an emulation of that mode's storage precision, used to tell rounding that is
         # inherent to bf16 storage from kernel error (tests/test_gpu_bench_config.py, tools/bf16_grad_ablation.py).
         self.act_dtype = act_dtype
+        # None: every storage point rounds.  A collection of stage-name prefixes ("enc.b3", "enc.pool", "dec.enc", "w.enc.b0" ...):
+        # only the storage points whose tag starts with one of them round (tools/bf16_stage_ablation.py localises which stage's
+        # storage rounding produces the embedding / gradient error of the bf16 mode).  `self.scope` is the model-level prefix the
+        # encoder / decoder entry points set ("style", "content", "dec").
+        self.act_stages = None if act_stages is None else tuple(act_stages)
+        self.scope = ""
+
+    def rounds(self, stage):
+        if self.act_dtype is None:
+            return False
+        if self.act_stages is None:
+            return True
+        tag = f"{self.scope}.{stage}" if stage else self.scope
+        return any(tag.startswith(p) or (stage or "").startswith(p) for p in self.act_stages)
 
 
 class _RoundST(torch.autograd.Function):
@@ -63,14 +77,14 @@ class _RoundST(torch.autograd.Function):
         return (g.to(ctx.dtype).to(g.dtype) if ctx.round_grad else g), None, None
 
 
-def _q(x, cfg: Cfg):
+def _q(x, cfg: Cfg, stage=None):
     """activation storage point"""
-    return x if cfg.act_dtype is None else _RoundST.apply(x, cfg.act_dtype, True)
+    return _RoundST.apply(x, cfg.act_dtype, True) if cfg.rounds(stage) else x
 
 
-def _qw(w, cfg: Cfg):
+def _qw(w, cfg: Cfg, stage=None):
     """packed-weight storage point (the weight GRADIENT is accumulated in f32: no rounding backward)"""
-    return w if cfg.act_dtype is None else _RoundST.apply(w, cfg.act_dtype, False)
+    return _RoundST.apply(w, cfg.act_dtype, False) if cfg.rounds("w." + (stage or "")) else w
 
 
 def _drop(x, cfg: Cfg):
@@ -100,14 +114,14 @@ def spectral_weight(sd, prefix: str, cfg: Cfg, dim: int = 0):
     return w / sigma
 
 
-def conv_sn(sd, prefix, x, cfg, stride=1, padding=0):
-    return _q(F.conv2d(x, _qw(spectral_weight(sd, prefix, cfg), cfg), sd[prefix + "bias"], stride=stride, padding=padding), cfg)
+def conv_sn(sd, prefix, x, cfg, stride=1, padding=0, stage=None):
+    return _q(F.conv2d(x, _qw(spectral_weight(sd, prefix, cfg), cfg, stage), sd[prefix + "bias"], stride=stride, padding=padding), cfg, stage)
 
 
-def convT_sn(sd, prefix, x, cfg, stride=1, padding=0, output_padding=0):
-    w = _qw(spectral_weight(sd, prefix, cfg, dim=1), cfg)
+def convT_sn(sd, prefix, x, cfg, stride=1, padding=0, output_padding=0, stage=None):
+    w = _qw(spectral_weight(sd, prefix, cfg, dim=1), cfg, stage)
     return _q(F.conv_transpose2d(x, w, sd[prefix + "bias"], stride=stride, padding=padding,
-                                 output_padding=output_padding), cfg)
+                                 output_padding=output_padding), cfg, stage)
 
 
 # --------------------------------------------------------------------------
@@ -245,26 +259,26 @@ def positional_encoding(L, d, dtype=torch.float32):
 # --------------------------------------------------------------------------
 # encoders
 # --------------------------------------------------------------------------
-def resblock(sd, prefix, x, cfg, stride=2):
+def resblock(sd, prefix, x, cfg, stride=2, stage=None):
     """style_encoder.py:41-84."""
-    idn = conv_sn(sd, prefix + "downsample.0.", x, cfg, stride=stride, padding=0)
+    idn = conv_sn(sd, prefix + "downsample.0.", x, cfg, stride=stride, padding=0, stage=stage)
     idn = instancenorm2d(sd, prefix + "downsample.1.", idn)
-    out = conv_sn(sd, prefix + "conv1.", x, cfg, stride=stride, padding=1)
-    out = _q(torch.relu(batchnorm2d(sd, prefix + "bn1.", out, cfg)), cfg)
-    out = conv_sn(sd, prefix + "conv2.", out, cfg, stride=1, padding=1)
+    out = conv_sn(sd, prefix + "conv1.", x, cfg, stride=stride, padding=1, stage=stage)
+    out = _q(torch.relu(batchnorm2d(sd, prefix + "bn1.", out, cfg)), cfg, stage)
+    out = conv_sn(sd, prefix + "conv2.", out, cfg, stride=1, padding=1, stage=stage)
     out = batchnorm2d(sd, prefix + "bn2.", out, cfg)
-    return _q(torch.relu(out + idn), cfg)
+    return _q(torch.relu(out + idn), cfg, stage)
 
 
 def deep_cnn(sd, net_prefix, proj_prefix, x, cfg, nblocks=6, return_blocks=False):
     """style_encoder.py:95-129 / content_encoder.py:22-46,80-85."""
     feats = []
-    x = _q(x, cfg)
+    x = _q(x, cfg, "in")
     for i in range(nblocks):
-        x = resblock(sd, f"{net_prefix}{i}.", x, cfg)
+        x = resblock(sd, f"{net_prefix}{i}.", x, cfg, stage=f"b{i}")
         feats.append(x)
-    x = _q(adaptive_avg_pool2d(x, (2, 5)), cfg)
-    x = _q(adaptive_avg_pool2d(x, (1, 1)), cfg).flatten(1)
+    x = _q(adaptive_avg_pool2d(x, (2, 5)), cfg, "pool")
+    x = _q(adaptive_avg_pool2d(x, (1, 1)), cfg, "pool").flatten(1)
     out = linear(sd, proj_prefix, x)
     return (out, feats) if return_blocks else out
 
@@ -278,6 +292,7 @@ def _encoder_stack(sd, seq, nhead, nlayers, cfg):
 def style_encoder_forward(sd, x, labels: Optional[torch.Tensor], cfg, nhead=4, nlayers=4):
     """style_encoder.py:199-258."""
     B, S = x.shape[:2]
+    cfg.scope = "style"
     feat = deep_cnn(sd, "cnn.net.", "cnn.proj.", x.reshape(B * S, *x.shape[2:]), cfg)
     seq = feat.view(B, S, -1)
     seq = torch.cat([sd["cls_token"].expand(B, -1, -1), seq], dim=1)
@@ -294,6 +309,7 @@ def style_encoder_forward(sd, x, labels: Optional[torch.Tensor], cfg, nhead=4, n
 def content_encoder_forward(sd, x, cfg, nhead=4, nlayers=4):
     """content_encoder.py:70-99."""
     B, S = x.shape[:2]
+    cfg.scope = "content"
     feat = deep_cnn(sd, "cnn.", "proj.", x.reshape(B * S, *x.shape[2:]), cfg)
     seq = feat.view(B, S, -1)
     seq = seq + positional_encoding(S, seq.shape[2])
@@ -306,25 +322,27 @@ def content_encoder_forward(sd, x, cfg, nhead=4, nlayers=4):
 # --------------------------------------------------------------------------
 def decoder_encode_input(sd, y, cfg):
     """new_decoder.py:145-168 -- y: (N,2,287,513) -> (N,256)."""
-    h = _q(y, cfg)
+    cfg.scope = "dec"
+    h = _q(y, cfg, "in")
     for idx, stride in ((0, 1), (3, 2), (6, 2), (9, 2)):
-        h = conv_sn(sd, f"conv_encoder.{idx}.", h, cfg, stride=stride, padding=1)
-        h = _q(torch.relu(batchnorm2d(sd, f"conv_encoder.{idx + 1}.", h, cfg)), cfg)
-    h = _q(adaptive_avg_pool2d(h, (32, 16)), cfg)
-    h = conv_sn(sd, "spatial_projection.0.", h, cfg, stride=1, padding=1)
-    h = _q(torch.relu(batchnorm2d(sd, "spatial_projection.1.", h, cfg)), cfg)
-    h = conv_sn(sd, "spatial_projection.3.", h, cfg, stride=1, padding=0)
+        h = conv_sn(sd, f"conv_encoder.{idx}.", h, cfg, stride=stride, padding=1, stage=f"enc{idx}")
+        h = _q(torch.relu(batchnorm2d(sd, f"conv_encoder.{idx + 1}.", h, cfg)), cfg, f"enc{idx}")
+    h = _q(adaptive_avg_pool2d(h, (32, 16)), cfg, "encpool")
+    h = conv_sn(sd, "spatial_projection.0.", h, cfg, stride=1, padding=1, stage="sp")
+    h = _q(torch.relu(batchnorm2d(sd, "spatial_projection.1.", h, cfg)), cfg, "sp")
+    h = conv_sn(sd, "spatial_projection.3.", h, cfg, stride=1, padding=0, stage="sp")
     return linear(sd, "feature_to_sequence.", h.flatten(1))
 
 
 def decoder_generate_output(sd, tok, cfg):
     """new_decoder.py:170-193 -- tok: (B,S,256) -> (B,S,2,287,513)."""
     B, S, _ = tok.shape
-    h = _q(linear(sd, "sequence_to_feature.", layernorm(sd, "output_norm.", tok)).view(B * S, 1, 32, 16), cfg)
+    cfg.scope = "dec"
+    h = _q(linear(sd, "sequence_to_feature.", layernorm(sd, "output_norm.", tok)).view(B * S, 1, 32, 16), cfg, "gen_in")
     for idx in (0, 3, 6, 9):
-        h = convT_sn(sd, f"conv_decoder.{idx}.", h, cfg, stride=2, padding=1, output_padding=1)
-        h = _q(torch.relu(batchnorm2d(sd, f"conv_decoder.{idx + 1}.", h, cfg)), cfg)
-    h = convT_sn(sd, "conv_decoder.12.", h, cfg, stride=1, padding=1)
+        h = convT_sn(sd, f"conv_decoder.{idx}.", h, cfg, stride=2, padding=1, output_padding=1, stage=f"gen{idx}")
+        h = _q(torch.relu(batchnorm2d(sd, f"conv_decoder.{idx + 1}.", h, cfg)), cfg, f"gen{idx}")
+    h = convT_sn(sd, "conv_decoder.12.", h, cfg, stride=1, padding=1, stage="gen12")
     return bilinear_resize(h, (287, 513)).view(B, S, 2, 287, 513)
 
 

@@ -1,0 +1,24 @@
+"""Stream fork / join patterns inside a hipGraph capture, model-free (tools/capture_forks.py): the captured train step forks
+and joins up to ~20 streams (encoder branches, discriminator phase, per-bank flushes, weight prepare), and round 2 lost two
+experiments to segmentation faults inside hipStreamEndCapture.  Every pattern runs in its own process (a crash must be an
+assertion here, not the end of the test session)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "tools", "capture_forks.py")
+
+
+def _run(pattern, n):
+    return subprocess.run([sys.executable, TOOL, pattern, str(n)], capture_output=True, text=True, timeout=300)
+
+
+@pytest.mark.parametrize("pattern,n", [("seq", 32), ("fan", 24), ("keep", 24), ("nested", 16), ("bwd", 32), ("bwd_leaf", 32)])
+def test_joined_fork_patterns_capture_and_replay(pattern, n):
+    r = _run(pattern, n)
+    assert r.returncode == 0 and f"OK {pattern} {n}" in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-1500:])

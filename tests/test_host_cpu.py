@@ -157,3 +157,58 @@ def test_length_bucket_sampler_and_section_counts():
     assert len(set(flat)) == len(flat)
     sm.set_epoch(1)
     assert list(sm) != batches                            # reshuffled per epoch
+
+
+def test_igemm_argument_validation_returns_error_codes():
+    """ast_igemm / ast_igemm_bn must refuse bad workspace / statistics arguments with an error code on EVERY kernel path
+    (gathered, direct, patch): a null or short workspace reaching a launch is a write through a bad device pointer, i.e. a GPU
+    fault.  All of these return before any launch, so fake non-null pointers are never dereferenced (host logic only)."""
+    import ctypes
+    lib = _lib.lib()
+    fake = 0x10000                                     # non-null, never dereferenced: every call below must fail validation
+    bf16 = _lib.BF16
+
+    def igemm(g, flags, ws, ws_floats):
+        return lib.ast_igemm(fake, fake, None, fake, g, bf16, flags, ws, ws_floats, None)
+
+    def igemm_bn(g, flags, ws, ws_floats, bn_x=fake, sc=fake, sf=fake):
+        return lib.ast_igemm_bn(fake, fake, None, fake, g, bf16, flags, ws, ws_floats, bn_x, sc, sf, None)
+
+    # (1) a split-K plan: the 3x3 conv 64 -> 8 channels on 16 x (32 x 16) pixels (spatial_projection-like, M = 8192)
+    gs, _ = ops.gather_direct(16, 32, 16, 64, 8, 3, 1, 1)
+    need = int(lib.ast_igemm_ws_floats(gs, bf16))
+    assert need == 16 * 32 * 16 * 8, need              # the premise: this geometry splits K
+    assert igemm(gs, 4, None, need) != 0               # null workspace
+    assert b"workspace" in lib.ast_last_error()
+    assert igemm(gs, 4, fake, need - 1) != 0           # short workspace
+    assert igemm(gs, 8, fake, need) != 0               # fused forward statistics on a split plan
+    assert b"split-K" in lib.ast_last_error()
+    assert igemm_bn(gs, 16, fake, need) != 0           # fused backward sums on a split plan
+    # (2) the gathered kernel without split: stride-2 3x3, 32 -> 64 channels on 16 x (144 x 299) (ResBlock b1 conv1)
+    gg, _ = ops.gather_direct(16, 144, 299, 32, 64, 3, 2, 1)
+    out = (ctypes.c_int32 * 5)()
+    assert lib.ast_igemm_plan(gg, bf16, ctypes.byref(out)) == 0 and out[2] > 0 and out[3] == 1, list(out)   # gathered, no split
+    assert int(lib.ast_igemm_ws_floats(gg, bf16)) == 0
+    assert igemm(gg, 8, None, 64 * 64 * 2) != 0        # statistics table missing
+    assert igemm(gg, 8, fake, 64 * 64 * 2 - 1) != 0    # ... too small
+    assert igemm(gg, 8 | 1, fake, 64 * 64 * 2) != 0    # ... with accumulate
+    assert igemm(gg, 64, fake, 16 * 64 * 2) != 0       # per-image slots without flag 8
+    assert igemm(gg, 8 | 64, fake, 16 * 64 * 2 - 1) != 0
+    assert igemm_bn(gg, 16, None, 64 * 64 * 3) != 0    # backward sums: table missing
+    assert igemm_bn(gg, 16, fake, 64 * 64 * 3 - 1) != 0
+    assert igemm_bn(gg, 16, fake, 64 * 64 * 3, bn_x=None) != 0
+    assert igemm_bn(gg, 16, fake, 64 * 64 * 3, sc=None) != 0
+    assert igemm_bn(gg, 16, fake, 64 * 64 * 3, sf=None) != 0
+    assert igemm_bn(gg, 16 | 2, fake, 64 * 64 * 3) != 0
+    # (3) the direct (LDS-free) kernel: 3x3, 8 -> 16 channels
+    gd, _ = ops.gather_direct(2, 64, 64, 8, 16, 3, 1, 1)
+    assert lib.ast_igemm_plan(gd, bf16, ctypes.byref(out)) == 0 and out[2] == 0, list(out)
+    assert igemm(gd, 8, None, 64 * 16 * 2) != 0
+    assert igemm_bn(gd, 16, fake, 64 * 16 * 3, bn_x=None) != 0
+    # (4) the patch kernel keeps its own checks: stride-1 3x3, 64 -> 64 channels
+    gp, _ = ops.gather_direct(16, 72, 150, 64, 64, 3, 1, 1)
+    assert lib.ast_igemm_plan(gp, bf16, ctypes.byref(out)) == 0 and out[2] < 0, list(out)
+    assert igemm(gp, 8, None, 64 * 64 * 2) != 0
+    assert igemm_bn(gp, 16, fake, 64 * 64 * 3, sf=None) != 0
+    # null geometry / tensors
+    assert lib.ast_igemm(None, fake, None, fake, gg, bf16, 0, None, 0, None) != 0
