@@ -39,6 +39,8 @@ class WeightBank:
         self._pin_used = 0
         self._conv_dirty = False
         self.d_train = self.d_eval = None
+        self._dev_consts = {}         # content -> device tensor (descriptor tables, tile lists): see _const_dev
+        self._packed = {}             # (entry index, dtype, size) -> the entry's packed images and scratch
         self.hold = False     # True: packed images are current (several forwards between optimiser steps)
 
     def add(self, weight, kind, dtype_fn, u=None, v=None, bias=None, rows=None):
@@ -47,6 +49,17 @@ class WeightBank:
         self.specs.append((weight, kind, dtype_fn, u, v, bias, rows))
         self.entries.append(PackedWeight())
         return self.entries[-1]
+
+    def _const_dev(self, payload: bytes, dtype, dev):
+        """Device copy of a small constant table, keyed by CONTENT and never freed.  A captured hipGraph bakes the ADDRESSES of
+        the bank's descriptor / tile / dtype tables into its kernel nodes: rebuilding the bank (an eval pass between two
+        training steps, a compute-dtype switch and back) must hand the same bytes back at the same address, and must not free
+        what an older graph still reads -- a replay after such a rebuild read a freed tile list and faulted the GPU."""
+        key = (payload, dtype, str(dev))
+        t = self._dev_consts.get(key)
+        if t is None:
+            t = self._dev_consts[key] = torch.frombuffer(bytearray(payload), dtype=dtype).to(dev)
+        return t
 
     def _signature(self, training):
         return (training,) + tuple((w.data_ptr(), w.device, fn(), (None if w.grad is None else w.grad.data_ptr()) if training else 0)
@@ -87,12 +100,16 @@ class WeightBank:
                 Co, KK, s_co, s_ci, w_off, b_off = r1 - r0, 1, Ci, 1, r0 * Ci, r0
             n = pad8(Co) * KK * pad8(Ci)
             if e.wf is None or e.wf.device != dev or e.wf.dtype != dt or e.wf.numel() != n:
-                e.wf = torch.empty(n, dtype=dt, device=dev)
-                e.wb = torch.empty(n, dtype=dt, device=dev)
-                e.sigma = torch.ones(1, dtype=torch.float32, device=dev)
-                e.scratch = torch.zeros(int(lib().ast_sn_scratch_floats(Co, Ci * KK)), dtype=torch.float32, device=dev)
-                e.gtmp = torch.zeros(1, dtype=torch.float32, device=dev)
-                e.bias_pad = torch.zeros(pad8(Co), dtype=torch.float32, device=dev) if (bias is not None and Co != pad8(Co)) else None
+                # one set of packed images per (entry, dtype), kept for the bank's lifetime: graphs captured in the other
+                # compute dtype keep reading theirs
+                pk = (len(descs), dt, n, str(dev))
+                if pk not in self._packed:
+                    self._packed[pk] = (torch.empty(n, dtype=dt, device=dev), torch.empty(n, dtype=dt, device=dev),
+                                        torch.ones(1, dtype=torch.float32, device=dev),
+                                        torch.zeros(int(lib().ast_sn_scratch_floats(Co, Ci * KK)), dtype=torch.float32, device=dev),
+                                        torch.zeros(1, dtype=torch.float32, device=dev),
+                                        torch.zeros(pad8(Co), dtype=torch.float32, device=dev) if (bias is not None and Co != pad8(Co)) else None)
+                e.wf, e.wb, e.sigma, e.scratch, e.gtmp, e.bias_pad = self._packed[pk]
             e.weight, e.u, e.v, e.bias, e.bank = w, u, v, bias, self
             e.Co, e.Ci, e.KK, e.s_co, e.s_ci, e.w_off, e.b_off = Co, Ci, KK, s_co, s_ci, w_off, b_off
             e.Cop, e.Cip, e.dtype = pad8(Co), pad8(Ci), dt
@@ -121,15 +138,16 @@ class WeightBank:
                     tl += [wi, co0, ci0, 0]
         if self._pin_pool is None:
             self._pin_pool = torch.empty(256 * 1024, dtype=torch.uint8, pin_memory=True)
+        import array
         self.ntiles = len(tl) // 4
-        self.d_tiles = torch.tensor(tl, dtype=torch.int32, device=dev)
+        self.d_tiles = self._const_dev(array.array("i", tl).tobytes(), torch.int32, dev)
         arr = (WeightDesc * len(descs))(*descs)
-        dev_descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        dev_descs = self._const_dev(bytes(arr), torch.uint8, dev)
         if training:
             self.d_train = dev_descs
         else:
             self.d_eval = dev_descs
-        self.d_dtypes = torch.tensor(dts, dtype=torch.int32, device=dev)
+        self.d_dtypes = self._const_dev(array.array("i", dts).tobytes(), torch.int32, dev)
         self._keys[training] = self._signature(training)
 
     def prepare(self, training: bool):

@@ -12,65 +12,10 @@
 // both, only the MFMA differs.  Weights are the MFMA "A" operand, so D[row][col]
 // has the output CHANNEL on the register index: each lane owns 4 consecutive
 // channels of one pixel and stores them with one 8/16-byte store into NHWC.
-#include <type_traits>
-#include "ast_common.h"
-#include "../../include/ast_hip.h"
+#include "gemm_common.h"
 
 namespace {
 
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  using frag = bf16x8;
-  static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  using frag = f32x4;
-  // lane (r, g) holds k = 4g+e (e = 0..3) of its row; step e contracts over g.
-  static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
-    return c;
-  }
-};
-
-struct RowPix { int off, hs0, ws0; bool valid; };
-
-__device__ __forceinline__ void decode_tap(int tp, int& dh, int& dw, int& wt) {
-  dh = (tp & 255) - 64; dw = ((tp >> 8) & 255) - 64; wt = tp >> 16;
-}
-
-// Epilogue helper: lane owns 4 consecutive channels of one destination pixel.
-template <typename T>
-__device__ __forceinline__ void store4(T* p, float (&v)[4], bool accumulate, bool relu) {
-  if constexpr (sizeof(T) == 4) {
-    f32x4* q = reinterpret_cast<f32x4*>(p);
-    if (accumulate) { const f32x4 o = *q; for (int r = 0; r < 4; ++r) v[r] += o[r]; }
-    if (relu) for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-    *q = f32x4{v[0], v[1], v[2], v[3]};
-  } else {
-    bf16x4* q = reinterpret_cast<bf16x4*>(p);
-    if (accumulate) { const bf16x4 o = *q; for (int r = 0; r < 4; ++r) v[r] += (float)o[r]; }
-    if (relu) for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-    *q = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-  }
-}
-
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-
-// floor(n / d) for 0 <= n < 2^31 through a float reciprocal (+-1 fix-up); integer division costs ~40 VALU.
-__device__ __forceinline__ int fdiv(int n, int d, float rcp) {
-  if (d == 1) return n;
-  int q = (int)((float)n * rcp);
-  int r = n - q * d;
-  if (r < 0) { --q; r += d; }
-  if (r < 0) { --q; r += d; }
-  if (r >= d) { ++q; r -= d; }
-  if (r >= d) ++q;
-  return q;
-}
 
 // LDS image: unpadded 64-byte rows (4 chunks of 16 B); chunk c of row r lives in slot (c + 2*((r>>3)&1)) & 3.
 // With ds_read_b128's 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (lane = row + 16*chunk) this
@@ -626,600 +571,6 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
     if (bias) for (int r = 0; r < 4; ++r) v[r] += bias[co + r];
     store4<T>(dst + pix * g.Cd + co, v, flags & 1, flags & 2);
   }
-}
-
-// ---------------------------------------------------------------------------
-// weight gradient: dw[cd][wtap][c] += sum_pix dy[pix][cd] * src[gather(pix,tap)][c]
-// A workgroup owns BMW output channels x NCT*16 columns of the (tap, channel) space -- ALL columns
-// when they fit (<= 320), so dy is read once instead of once per 64-column tile -- and a slice of the
-// pixels (grid.z); partial tiles are added with f32 atomics (dw is zeroed by the caller).
-// Per K tile (BKP pixels) a thread decodes ONE pixel row and fetches its strided set of 16-byte
-// chunks with buffer loads (hardware zero-fill outside the image).  LDS holds [pixel][channel]
-// images; the MFMA operands need [channel][pixel]: bf16 through ds_read_b64_tr_b16 (hardware
-// transpose), f32 through ds_read_b32 (one element per lane per MFMA).
-// ---------------------------------------------------------------------------
-#ifdef AST_STAMPS
-__device__ unsigned long long ast_wg_stamps[4096 * 8];      // wgrad_kernel phase stamps (tools/wgrad_stamps.py)
-__device__ long long ast_wg_phase[4096 * 4];                // K-loop sub-phases: load issue, reads + MFMA, second barrier, trips
-#define WG_STAMP(k) do { if (threadIdx.x == 0 && tix < 4096) ast_wg_stamps[tix * 8 + (k)] = (k) >= 6 ? wall_clock64() : __builtin_readcyclecounter(); } while (0)
-#else
-#define WG_STAMP(k) do { } while (0)
-#endif
-// Gradient replicas (ast_wgrad_rep): workgroups of pixel slice z add their tile into copy z % nrep of dw (copies nrep_stride
-// floats apart); whoever reads dw sums the copies (ast_weight_grads_flush_t).  Same-address f32 atomics serialise at ~155 ns
-// each wherever the address lives (tools/micro/l2atomic.hip: spreading the lines over channels or doing them at L2 level
-// changes nothing), so the flush of 85 workgroups per tile took 14 us of a 40 us launch (tools/wgrad_stamps.py); with 8
-// copies the chains are 11 deep.
-static thread_local int g_wg_nrep = 1;
-static thread_local long g_wg_rep_stride = 0;
-template <typename T> struct WgradCfg;
-template <> struct WgradCfg<bf16_t> { static constexpr int BKP = 64, PAD = 16; };   // elements: row pitch = 32 B x odd for rows that are multiples of 64 B (see SWZ)
-template <> struct WgradCfg<float> { static constexpr int BKP = 32, PAD = 16; };
-
-// PG pixel groups of 4 waves per workgroup, as in wgrad_halo_kernel: group pg takes every PG-th K tile of the workgroup's pixel
-// slice through its own LDS staging, partial tiles are summed through LDS, one atomic flush per workgroup.
-template <typename T, int BMW, int NCT, int PG>
-__global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ src,
-                                                     float* __restrict__ dw, const ast_gather_t g,
-                                                     const int P, const int pps, const unsigned dy_bytes,
-                                                     const unsigned src_bytes, const float rcp_hw, const float rcp_w,
-                                                     const int gx, const int gy, const int gz, const int nrep, const long rep_stride) {
-  constexpr int E = 16 / sizeof(T), ES = sizeof(T);
-  constexpr int BKP = WgradCfg<T>::BKP, PAD = WgradCfg<T>::PAD;
-  constexpr int BNW = NCT * 16;
-  constexpr int TPR = 256 / BKP;                    // threads per pixel row
-  constexpr int CPX = BNW / E, CPY = BMW / E;       // 16-byte chunks per row
-  constexpr int NXI = (CPX + TPR - 1) / TPR, NYI = (CPY + TPR - 1) / TPR;
-  constexpr int PX = BNW + PAD, PY = BMW + PAD;     // LDS pitches (elements)
-  constexpr bool SWZ = sizeof(T) == 2 && (CPX % 2 == 0) && (CPY % 2 == 0);
-  constexpr int RT = BMW / 16;                      // row (cd) tiles, all handled by every wave
-  constexpr int CTW = (NCT + 3) / 4;                // column tiles per wave
-  constexpr unsigned OOB = 0x80000000u;
-  extern __shared__ __attribute__((aligned(16))) unsigned char wl_all[];
-  constexpr int GROUP_BYTES = (int)sizeof(T) * BKP * (PY + PX);
-  constexpr int RED = PG > 1 ? RT * CTW * 256 * 16 : 0;                        // one group's partial tile in the final LDS reduction
-  constexpr int TAP_OFF = (PG * GROUP_BYTES > RED ? PG * GROUP_BYTES : RED);
-  const int pg = PG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
-  unsigned char* wl = wl_all + pg * GROUP_BYTES;
-  T* Ys = reinterpret_cast<T*>(wl);
-  T* Xs = Ys + BKP * PY;
-  int* taptab = reinterpret_cast<int*>(wl_all + TAP_OFF);
-
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-  // XCD-aware order (workgroups b and b+8 share an L2): XCD x takes the x-th contiguous eighth of the tiles in
-  // (row tile, pixel slice, column tile) order, so an L2 holds ONE channel slice of dy (deep layers: Cd/64 >= 8 row
-  // tiles) or ONE band of pixels (shallow layers: many pixel slices) instead of a sample of the whole layer.  Measured
-  // before: 64 MB of fabric reads per launch for 25 MB algorithmic (profiles/r01/d_pmc_traffic.json).
-  const int chunk = gridDim.x >> 3;
-  const int tix = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (tix >= gx * gy * gz) return;
-  WG_STAMP(0); WG_STAMP(7);
-  const int bx = tix / (gz * gy), bz = (tix / gy) % gz, by = tix % gy;
-  const int cd0 = bx * BMW, col0 = by * BNW;
-  const int ncols = g.ntaps * g.Cs;
-  const int HWm = g.Hm * g.Wm;
-  const int p_begin = bz * pps, p_end = min(P, p_begin + pps);
-  const __amdgpu_buffer_rsrc_t dyR = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t srcR = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, src_bytes, 0x00020000);
-#pragma unroll
-  for (int t = 0; t < AST_MAX_TAPS; ++t)
-    if ((int)threadIdx.x == t) taptab[t] = g.tap[t];
-  __syncthreads();
-
-  // loader role: one pixel row per thread, chunks tq, tq + TPR, ...
-  const int lrow = tid / TPR, tq = tid % TPR;
-  int xdelta[NXI], xdh[NXI], xdw[NXI];              // per chunk slot: byte delta of (tap, channel), tap offsets; dh = 1<<20 marks "no column"
-#pragma unroll
-  for (int i = 0; i < NXI; ++i) {
-    const int ch = tq + TPR * i, col = col0 + ch * E;
-    xdelta[i] = 0; xdh[i] = 1 << 20; xdw[i] = 0;
-    if (ch < CPX && col < ncols) {
-      const int t = col / g.Cs, c = col - t * g.Cs;
-      int dh, dw_, wt;
-      decode_tap(taptab[t], dh, dw_, wt);
-      xdh[i] = dh; xdw[i] = dw_;
-      xdelta[i] = ((dh * g.Ws + dw_) * g.Cs + c) * ES;
-    }
-  }
-  u32x4 yreg[NYI], xreg[NXI];
-  auto load_tile = [&](int p0) __attribute__((always_inline)) {
-    const int p = p0 + lrow;
-    const bool pv = p < p_end;
-    const int pp = pv ? p : 0;
-#pragma unroll
-    for (int i = 0; i < NYI; ++i) {
-      const int ch = tq + TPR * i, cd = cd0 + ch * E;
-      const bool ok = pv && ch < CPY && cd < g.Cd;
-      yreg[i] = __builtin_amdgcn_raw_buffer_load_b128(dyR, ok ? (unsigned)((pp * g.Cd + cd) * ES) : OOB, 0, 0);
-    }
-    const int n = fdiv(pp, HWm, rcp_hw), rem = pp - n * HWm;
-    const int hm = fdiv(rem, g.Wm, rcp_w), wq = rem - hm * g.Wm;
-    const int hs0 = pv ? hm * g.sh + g.oh : -(1 << 21), ws0 = wq * g.sw + g.ow;
-    const int base = (((n * g.Hs + hs0) * g.Ws + ws0) * g.Cs) * ES;
-#pragma unroll
-    for (int i = 0; i < NXI; ++i) {
-      const bool ok = (unsigned)(hs0 + xdh[i]) < (unsigned)g.Hs && (unsigned)(ws0 + xdw[i]) < (unsigned)g.Ws;
-      xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srcR, ok ? (unsigned)(base + xdelta[i]) : OOB, 0, 0);
-    }
-  };
-  auto store_tile = [&]() __attribute__((always_inline)) {
-    // bf16: 32-byte column segments are XOR-swizzled by bit 3 of the pixel row (SWZ): the transposed reads of a half-wave touch
-    // rows r..r+3 and r+8..r+11, which a pitch of 32 B x odd alone leaves on the same banks.  Measured: 128-channel layer
-    // 50.3 -> 48.4 us, 256-channel 47.1 -> 45.1, 512-channel 41.6 -> 39.0 (the pitch change alone: nothing); the
-    // SQ_LDS_BANK_CONFLICT count of the launch did not move (3.89 M, five per MFMA), so that counter is not what it measures
-    const int sw = SWZ ? ((lrow >> 3) & 1) << 1 : 0;             // in 16-byte chunks
-#pragma unroll
-    for (int i = 0; i < NYI; ++i) {
-      const int ch = tq + TPR * i;
-      if (ch < CPY) *reinterpret_cast<u32x4*>(Ys + lrow * PY + (ch ^ sw) * E) = yreg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NXI; ++i) {
-      const int ch = tq + TPR * i;
-      if (ch < CPX) *reinterpret_cast<u32x4*>(Xs + lrow * PX + (ch ^ sw) * E) = xreg[i];
-    }
-  };
-
-  f32x4 acc[RT][CTW];
-#pragma unroll
-  for (int i = 0; i < RT; ++i)
-#pragma unroll
-    for (int j = 0; j < CTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int li = lane & 15, gq = lane >> 4;
-  const int nk_all = (p_end - p_begin + BKP - 1) / BKP;
-  const int nk = (nk_all + PG - 1) / PG;                         // trips: every group runs all of them (workgroup-wide barriers);
-  if (nk > 0) load_tile(p_begin + pg * BKP);                    // a group past the slice's end loads zeros (p >= p_end)
-  WG_STAMP(1);
-#ifdef AST_STAMPS
-  long long ph[5] = {0, 0, 0, 0, 0};              // cycles of thread 0 in: LDS store (incl. the wait for the loads), barrier, load issue, reads + MFMA, barrier
-#define WG_PH(i) do { const long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tph; tph = t_; } while (0)
-  long long tph = __builtin_readcyclecounter();
-#else
-#define WG_PH(i) do { } while (0)
-#endif
-  for (int kt = 0; kt < nk; ++kt) {
-    store_tile();
-    WG_PH(0);
-    __syncthreads();
-    WG_PH(1);
-    if (kt + 1 < nk) load_tile(p_begin + ((kt + 1) * PG + pg) * BKP);       // in flight while this tile is consumed
-    WG_PH(2);
-    if constexpr (sizeof(T) == 2) {
-      typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-      const int q = li >> 2, pcol = (li & 3) * 4;                // lane 4q+p supplies row q, columns 4p..4p+3 of its 16-lane group
-#pragma unroll
-      for (int ks = 0; ks < BKP / 32; ++ks) {
-        const int r_lo = ks * 32 + 8 * gq + q;
-        const int sx = SWZ ? (gq & 1) << 4 : 0;                 // rows r_lo and r_lo + 4 share bit 3 = gq & 1 (elements)
-        bf16x8 af[RT];
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Ys + r_lo * PY + ((i * 16) ^ sx) + pcol));
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Ys + (r_lo + 4) * PY + ((i * 16) ^ sx) + pcol));
-          af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-#pragma unroll
-        for (int j = 0; j < CTW; ++j) {
-          const int ct = wave + 4 * j;                          // uniform per wave
-          if (ct < NCT) {
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xs + r_lo * PX + ((ct * 16) ^ sx) + pcol));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xs + (r_lo + 4) * PX + ((ct * 16) ^ sx) + pcol));
-            const bf16x8 bf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-            for (int i = 0; i < RT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int s4 = 0; s4 < BKP / 4; ++s4) {
-        float af[RT];
-#pragma unroll
-        for (int i = 0; i < RT; ++i) af[i] = Ys[(4 * s4 + gq) * PY + i * 16 + li];
-#pragma unroll
-        for (int j = 0; j < CTW; ++j) {
-          const int ct = wave + 4 * j;
-          if (ct < NCT) {
-            const float bf = Xs[(4 * s4 + gq) * PX + ct * 16 + li];
-#pragma unroll
-            for (int i = 0; i < RT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][j], 0, 0, 0);
-          }
-        }
-      }
-    }
-    WG_PH(3);
-    __syncthreads();                                             // operand reads done before the next store
-    WG_PH(4);
-  }
-#ifdef AST_STAMPS
-  if (threadIdx.x == 0 && tix < 4096) { ast_wg_stamps[tix * 8 + 5] = (unsigned long long)((ph[0] << 32) | (ph[1] & 0xffffffffll)); ast_wg_phase[tix * 4 + 0] = ph[2]; ast_wg_phase[tix * 4 + 1] = ph[3]; ast_wg_phase[tix * 4 + 2] = ph[4]; ast_wg_phase[tix * 4 + 3] = nk; }
-#endif
-
-  WG_STAMP(2);
-  if constexpr (PG > 1) {                           // sum the groups' partial tiles through LDS (the staging is free now)
-    f32x4* red = reinterpret_cast<f32x4*>(wl_all);
-#pragma unroll
-    for (int src_g = 1; src_g < PG; ++src_g) {
-      __syncthreads();
-      if (pg == src_g) {
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-          for (int j = 0; j < CTW; ++j) red[(i * CTW + j) * 256 + tid] = acc[i][j];
-      }
-      __syncthreads();
-      if (pg == 0) {
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-          for (int j = 0; j < CTW; ++j) {
-            const f32x4 t = red[(i * CTW + j) * 256 + tid];
-            acc[i][j][0] += t[0]; acc[i][j][1] += t[1]; acc[i][j][2] += t[2]; acc[i][j][3] += t[3];
-          }
-      }
-    }
-    if (pg > 0) return;
-  }
-  WG_STAMP(3);
-  dw += (size_t)(bz % nrep) * rep_stride;          // this pixel slice's gradient replica
-  // D[row = cd (gq*4+r)][col = column li]
-#pragma unroll
-  for (int j = 0; j < CTW; ++j) {
-    const int ct = wave + 4 * j;
-    const int col = col0 + ct * 16 + li;
-    if (ct >= NCT || col >= ncols) continue;
-    const int t = col / g.Cs, c = col - t * g.Cs;
-    int a, b, wtc;
-    decode_tap(taptab[t], a, b, wtc);
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cd = cd0 + i * 16 + gq * 4 + r;
-        if (cd < g.Cd) unsafeAtomicAdd(dw + ((size_t)cd * g.wtaps + wtc) * g.Cs + c, acc[i][j][r]);
-      }
-  }
-#ifdef AST_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the atomics have been acknowledged
-#endif
-  WG_STAMP(4); WG_STAMP(6);
-}
-#ifdef AST_STAMPS
-extern "C" int ast_debug_read_wg_stamps(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ast_wg_stamps), (size_t)n * 8 * sizeof(unsigned long long));
-}
-extern "C" int ast_debug_read_wg_phases(long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ast_wg_phase), (size_t)n * 4 * sizeof(long long));
-}
-#endif
-
-template <typename T, int BMW, int NCT, int PG>
-int launch_wgrad_pg(const void* dy, const void* src, float* dw, const ast_gather_t& g, int P, hipStream_t s) {
-  constexpr int BKP = WgradCfg<T>::BKP, PAD = WgradCfg<T>::PAD;
-  constexpr int GROUP = (int)sizeof(T) * BKP * ((BMW + PAD) + (NCT * 16 + PAD));
-  constexpr int RED = PG > 1 ? (BMW / 16) * ((NCT + 3) / 4) * 256 * 16 : 0;
-  constexpr int LDS = (PG * GROUP > RED ? PG * GROUP : RED) + 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    AST_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<T, BMW, NCT, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
-  const int gx = (g.Cd + BMW - 1) / BMW, gy = (g.ntaps * g.Cs + NCT * 16 - 1) / (NCT * 16);
-  const int tiles = gx * gy;
-  const char* wte = getenv("AST_WGRAD_WG_TARGET");
-  // see launch_wgrad_halo; the single-group 64 x 192 tiles (23 launches of a step) take 384: 29.5-29.8 -> 28.1-28.3 us on
-  // average in the replayed step (tools/knob_ab.sh; 320: 29.1, 448: 30.5), the two-group and the narrow ones do not (32.7 -> 43.3)
-  const int wg_target = wte ? atoi(wte) : (P >= 1500000 ? 768 : (PG == 1 && NCT >= 12 ? 384 : 256));
-  int nsplit = std::max(1, std::min((P + 4 * BKP - 1) / (4 * BKP), (wg_target + tiles - 1) / tiles));
-  int pps = (P + nsplit - 1) / nsplit;
-  pps = (pps + BKP - 1) / BKP * BKP;
-  nsplit = (P + pps - 1) / pps;
-  const unsigned dy_bytes = (unsigned)((size_t)P * g.Cd * sizeof(T));
-  const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
-  const int total = gx * gy * nsplit;
-  hipLaunchKernelGGL((wgrad_kernel<T, BMW, NCT, PG>), dim3((total + 7) / 8 * 8), dim3(256 * PG), LDS, s, (const T*)dy, (const T*)src, dw, g, P, pps,
-                     dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm, gx, gy, nsplit, g_wg_nrep, g_wg_rep_stride);
-  AST_CHECK_LAUNCH();
-  return 0;
-}
-
-template <typename T, int BMW, int NCT>
-int launch_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t& g, int P, hipStream_t s) {
-  // two pixel groups for the pixel-rich layers only: measured 172 800 pixels -11 % (51 -> 45 us), 43 200 pixels +20 %
-  // (54 -> 65 us: their slices are a few K tiles long, halving them leaves the groups idle at the barriers)
-  const char* pe = getenv("AST_WGRAD_PG");
-  const char* mp = getenv("AST_WGRAD_PG_MINP");
-  const int pg = pe ? atoi(pe) : 2;
-  if (pg >= 2 && P >= (mp ? atoi(mp) : 100000)) return launch_wgrad_pg<T, BMW, NCT, 2>(dy, src, dw, g, P, s);
-  return launch_wgrad_pg<T, BMW, NCT, 1>(dy, src, dw, g, P, s);
-}
-
-// ---------------------------------------------------------------------------
-// Halo-tile weight gradient for the small-channel layers (Cd <= 64, all (tap, channel) columns
-// <= 320 per workgroup).  The gathered kernel above fetches every source pixel once per tap
-// (9x for 3x3) and spends ~8 VALU per 16-byte chunk on addressing: ~1.5 VALU cycles per MFMA
-// cycle on these layers.  Here a workgroup walks 8x16-pixel tiles of dy: per tile it stages dy
-// (128 x Cd) and the source patch (tile + halo, each pixel ONCE) in LDS, and every tap's B operand
-// is a transposed read of the patch at a shifted address.  Accumulators stay in registers across
-// all tiles of the workgroup; one atomic flush at the end.
-// ---------------------------------------------------------------------------
-constexpr int WH_TH = 8, WH_TW = 16, WH_MAXPL = 10;
-struct WHaloPlan { int PH, PW, dhmin, dwmin, tiles_h, tiles_w, ntiles, lds; };
-
-// PG: pixel groups.  The workgroup has PG groups of 4 waves; group pg streams tiles blockIdx.z*PG + pg, + gridDim.z*PG, ...
-// through its OWN LDS staging and accumulators, and the groups' partial tiles are summed through LDS before ONE atomic flush per
-// workgroup.  Same-address f32 atomics serialise (~38 ns per workgroup per address on the 16x72 gradient of the 2.4 M-pixel
-// layer: 768 -> 3072 workgroups took 77 -> 164 us), so parallelism has to come from waves per workgroup, not from workgroups.
-template <typename T, int BMW, int NCT, int PG>
-__global__ __launch_bounds__(256 * PG) void wgrad_halo_kernel(const T* __restrict__ dy, const T* __restrict__ src,
-                                                          float* __restrict__ dw, const ast_gather_t g, const WHaloPlan hp,
-                                                          const unsigned dy_bytes, const unsigned src_bytes, const int nrep, const long rep_stride) {
-  constexpr int E = 16 / sizeof(T), ES = sizeof(T);
-  constexpr int MT = WH_TH * WH_TW;                 // 128 pixels per tile
-  constexpr int PADY = sizeof(T) == 2 ? 8 : 16;
-  constexpr int PY = BMW + PADY;                    // dy tile pitch (elements)
-  constexpr int CPY = BMW / E;                      // dy chunks per pixel
-  constexpr int NYI = (MT * CPY + 255) / 256;
-  constexpr int RT = BMW / 16, CTW = (NCT + 3) / 4;
-  constexpr unsigned OOB = 0x80000000u;
-  extern __shared__ __attribute__((aligned(16))) unsigned char wl_all[];
-  const int pg = PG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;      // wave-uniform
-  const int PPX = g.Cs + (sizeof(T) == 2 ? 8 : 4);  // patch pixel pitch (elements): breaks the power-of-two stride
-  const int group_bytes = ((int)sizeof(T) * (MT * PY + hp.PH * hp.PW * PPX) + 15) & ~15;
-  unsigned char* wl = wl_all + pg * group_bytes;
-  T* Ys = reinterpret_cast<T*>(wl);
-  T* Xp = Ys + MT * PY;                             // patch [PH*PW][Cs + pad]
-  constexpr int RED = PG > 1 ? (BMW / 16) * ((NCT + 3) / 4) * 256 * 16 : 0;     // bytes of one group's partial tile in the final LDS reduction
-  int* taptab = reinterpret_cast<int*>(wl_all + max(PG * group_bytes, RED));   // behind both uses of the staging area
-
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-  const int cd0 = blockIdx.x * BMW, col0 = blockIdx.y * NCT * 16;
-  const int ncols = g.ntaps * g.Cs;
-  const int UP = g.Cs / E;                          // 16-byte chunks per patch pixel
-  const int PH = hp.PH, PW = hp.PW;
-  const __amdgpu_buffer_rsrc_t dyR = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t srcR = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, src_bytes, 0x00020000);
-#pragma unroll
-  for (int t = 0; t < AST_MAX_TAPS; ++t)
-    if ((int)threadIdx.x == t) {
-      int dh, dwv, wt;
-      decode_tap(g.tap[t], dh, dwv, wt);
-      taptab[t] = ((dh - hp.dhmin) * PW + (dwv - hp.dwmin)) * PPX;   // patch element offset of the tap
-      taptab[16 + t] = wt;
-    }
-  __syncthreads();
-
-  // ---- loader descriptors: patch slots (py, px, part) and dy slots (pixel, chunk)
-  int ppy[WH_MAXPL], ppx[WH_MAXPL], pgo[WH_MAXPL], plo[WH_MAXPL];
-  const int npatch = PH * PW * UP;
-#pragma unroll
-  for (int i = 0; i < WH_MAXPL; ++i) {
-    const int idx = tid + 256 * i;
-    ppy[i] = -(1 << 20); ppx[i] = 0; pgo[i] = 0; plo[i] = -1;
-    if (idx < npatch) {
-      const int pix = idx / UP, part = idx - pix * UP;
-      ppy[i] = pix / PW; ppx[i] = pix - ppy[i] * PW;
-      pgo[i] = ((ppy[i] * g.Ws + ppx[i]) * g.Cs + part * E) * ES;
-      plo[i] = pix * PPX + part * E;
-    }
-  }
-  int ypix[NYI], ych[NYI];
-#pragma unroll
-  for (int i = 0; i < NYI; ++i) {
-    const int idx = tid + 256 * i;
-    ypix[i] = idx < MT * CPY ? idx / CPY : -1;
-    ych[i] = idx < MT * CPY ? idx % CPY : 0;
-  }
-  // ---- per-lane operand offsets
-  const int li = lane & 15, gq = lane >> 4;
-  int coloff[CTW];                                  // patch element offset of this lane's column (tap, channel) per column tile
-  bool colok[CTW];
-#pragma unroll
-  for (int j = 0; j < CTW; ++j) {
-    const int ct = wave + 4 * j;
-    const int col = col0 + ct * 16 + (sizeof(T) == 2 ? (li & 3) * 4 : li);
-    colok[j] = ct < NCT && col < ncols;
-    const int t = colok[j] ? col / g.Cs : 0;
-    coloff[j] = taptab[t] + (colok[j] ? col - t * g.Cs : 0);
-  }
-
-  f32x4 acc[RT][CTW];
-#pragma unroll
-  for (int i = 0; i < RT; ++i)
-#pragma unroll
-    for (int j = 0; j < CTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  u32x4 preg[WH_MAXPL], yreg[NYI];
-  auto load_tile = [&](int tile_in) __attribute__((always_inline)) {
-    const bool tvalid = tile_in < hp.ntiles;          // a group past its last tile loads zeros (every offset out of range)
-    const int tile = tvalid ? tile_in : 0;
-    const int per_img = hp.tiles_h * hp.tiles_w;
-    const int n = tile / per_img, r = tile - n * per_img;
-    const int th = r / hp.tiles_w, tw = r - th * hp.tiles_w;
-    const int hm0 = th * WH_TH, wm0 = tw * WH_TW;
-    const int hs_org = hm0 * g.sh + g.oh + hp.dhmin, ws_org = wm0 * g.sw + g.ow + hp.dwmin;
-    const int base = (((n * g.Hs + hs_org) * g.Ws + ws_org) * g.Cs) * ES;
-#pragma unroll
-    for (int i = 0; i < WH_MAXPL; ++i) {
-      const bool ok = tvalid && plo[i] >= 0 && (unsigned)(hs_org + ppy[i]) < (unsigned)g.Hs && (unsigned)(ws_org + ppx[i]) < (unsigned)g.Ws;
-      preg[i] = __builtin_amdgcn_raw_buffer_load_b128(srcR, ok ? (unsigned)(base + pgo[i]) : OOB, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NYI; ++i) {
-      const int ty = ypix[i] >> 4, tx = ypix[i] & 15;
-      const int hm = hm0 + ty, wq = wm0 + tx;
-      const int cd = cd0 + ych[i] * E;
-      const bool ok = tvalid && ypix[i] >= 0 && hm < g.Hm && wq < g.Wm && cd < g.Cd;
-      yreg[i] = __builtin_amdgcn_raw_buffer_load_b128(dyR, ok ? (unsigned)((((n * g.Hm + hm) * g.Wm + wq) * g.Cd + cd) * ES) : OOB, 0, 0);
-    }
-  };
-  auto store_tile = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < WH_MAXPL; ++i)
-      if (plo[i] >= 0) *reinterpret_cast<u32x4*>(Xp + plo[i]) = preg[i];
-#pragma unroll
-    for (int i = 0; i < NYI; ++i)
-      if (ypix[i] >= 0) *reinterpret_cast<u32x4*>(Ys + ypix[i] * PY + ych[i] * E) = yreg[i];
-  };
-
-  // every group runs the workgroup's trip count (the barriers are workgroup-wide); a group without a tile works on zeros
-  const int tstride = gridDim.z * PG;
-  const int first = blockIdx.z * PG;
-  const int ntrips = first < hp.ntiles ? (hp.ntiles - first + tstride - 1) / tstride : 0;
-  int tile = first + pg;
-  if (ntrips > 0) load_tile(tile);
-  for (int trip = 0; trip < ntrips; ++trip, tile += tstride) {
-    store_tile();
-    __syncthreads();
-    if (trip + 1 < ntrips) load_tile(tile + tstride);                        // next tile in flight during the MFMAs
-    if constexpr (sizeof(T) == 2) {
-      typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-      const int q = li >> 2, pcol = (li & 3) * 4;
-#pragma unroll
-      for (int ks = 0; ks < MT / 32; ++ks) {
-        // rows (pixels) of this lane's two 4-row blocks: p = 32 ks + 8 gq + q (+4); tile row = p >> 4, column = p & 15
-        const int p_lo = ks * 32 + 8 * gq + q, p_hi = p_lo + 4;
-        const int x_lo = (((p_lo >> 4) * g.sh) * PW + (p_lo & 15) * g.sw) * PPX;
-        const int x_hi = (((p_hi >> 4) * g.sh) * PW + (p_hi & 15) * g.sw) * PPX;
-        bf16x8 af[RT];
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Ys + p_lo * PY + i * 16 + pcol));
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Ys + p_hi * PY + i * 16 + pcol));
-          af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-#pragma unroll
-        for (int j = 0; j < CTW; ++j) {
-          if (wave + 4 * j < NCT) {                                         // uniform per wave; masked columns read a valid address
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xp + x_lo + coloff[j]));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(Xp + x_hi + coloff[j]));
-            const bf16x8 bf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-            for (int i = 0; i < RT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
-          }
-        }
-      }
-    } else {
-#pragma unroll 4
-      for (int s4 = 0; s4 < MT / 4; ++s4) {
-        const int p = 4 * s4 + gq;
-        const int xo = (((p >> 4) * g.sh) * PW + (p & 15) * g.sw) * PPX;
-        float af[RT];
-#pragma unroll
-        for (int i = 0; i < RT; ++i) af[i] = Ys[p * PY + i * 16 + li];
-#pragma unroll
-        for (int j = 0; j < CTW; ++j) {
-          if (wave + 4 * j < NCT) {
-            const float bf = colok[j] ? Xp[xo + coloff[j]] : 0.f;
-#pragma unroll
-            for (int i = 0; i < RT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[i][j], 0, 0, 0);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  if constexpr (PG > 1) {                           // sum the groups' partial tiles through LDS (the staging is free now)
-    f32x4* red = reinterpret_cast<f32x4*>(wl_all);
-#pragma unroll
-    for (int src_g = 1; src_g < PG; ++src_g) {
-      __syncthreads();
-      if (pg == src_g) {
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-          for (int j = 0; j < CTW; ++j) red[(i * CTW + j) * 256 + tid] = acc[i][j];
-      }
-      __syncthreads();
-      if (pg == 0) {
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-          for (int j = 0; j < CTW; ++j) {
-            const f32x4 t = red[(i * CTW + j) * 256 + tid];
-            acc[i][j][0] += t[0]; acc[i][j][1] += t[1]; acc[i][j][2] += t[2]; acc[i][j][3] += t[3];
-          }
-      }
-    }
-    if (pg > 0) return;
-  }
-  // D[row = cd (gq*4+r)][col = column li]
-  dw += (size_t)(blockIdx.z % nrep) * rep_stride;      // this slice's gradient replica (see g_wg_nrep)
-#pragma unroll
-  for (int j = 0; j < CTW; ++j) {
-    const int ct = wave + 4 * j;
-    const int col = col0 + ct * 16 + li;
-    if (ct >= NCT || col >= ncols) continue;
-    const int t = col / g.Cs, c = col - t * g.Cs;
-    const int wtc = taptab[16 + t];
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cd = cd0 + i * 16 + gq * 4 + r;
-        if (cd < g.Cd) unsafeAtomicAdd(dw + ((size_t)cd * g.wtaps + wtc) * g.Cs + c, acc[i][j][r]);
-      }
-  }
-}
-
-bool plan_wgrad_halo(const ast_gather_t& g, int dtype, int nct, int bmw, WHaloPlan& hp) {
-  const char* mc = getenv("AST_WGRAD_HALO_MAXCD");
-  if (g.ntaps < 2 || g.Cd > (mc ? atoi(mc) : 32)) return false;          // measured: wins for <= 32 output channels, loses at 64
-  const int E = dtype == AST_BF16 ? 8 : 4, ES = dtype == AST_BF16 ? 2 : 4;
-  int dhmin = 64, dhmax = -64, dwmin = 64, dwmax = -64;
-  for (int t = 0; t < g.ntaps; ++t) {
-    const int dh = (g.tap[t] & 255) - 64, dw = ((g.tap[t] >> 8) & 255) - 64;
-    dhmin = std::min(dhmin, dh); dhmax = std::max(dhmax, dh); dwmin = std::min(dwmin, dw); dwmax = std::max(dwmax, dw);
-  }
-  hp.dhmin = dhmin; hp.dwmin = dwmin;
-  hp.PH = (WH_TH - 1) * g.sh + (dhmax - dhmin) + 1;
-  hp.PW = (WH_TW - 1) * g.sw + (dwmax - dwmin) + 1;
-  if (hp.PH * hp.PW * (g.Cs / E) > 256 * WH_MAXPL) return false;
-  hp.tiles_h = (g.Hm + WH_TH - 1) / WH_TH; hp.tiles_w = (g.Wm + WH_TW - 1) / WH_TW;
-  hp.ntiles = g.N * hp.tiles_h * hp.tiles_w;
-  const int ppx = g.Cs + (ES == 2 ? 8 : 4), pady = ES == 2 ? 8 : 16;
-  hp.lds = ((ES * (WH_TH * WH_TW * (bmw + pady) + hp.PH * hp.PW * ppx) + 15) & ~15);      // one group's staging
-  if (hp.lds > 96 * 1024) return false;
-  // tile quantisation: skip when the 8x16 tiling wastes most of the work (tiny images go to the gathered kernel)
-  const double eff = (double)g.Hm * g.Wm / ((double)hp.tiles_h * hp.tiles_w * WH_TH * WH_TW);
-  return eff >= 0.6 && hp.ntiles >= 256;
-}
-
-template <typename T, int BMW, int NCT, int PG>
-int launch_wgrad_halo_pg(const void* dy, const void* src, float* dw, const ast_gather_t& g, const WHaloPlan& hp, hipStream_t s) {
-  constexpr int RED = (BMW / 16) * ((NCT + 3) / 4) * 256 * 16;          // bytes of one group's partial tile in the LDS reduction
-  const int lds = std::max(PG * hp.lds, PG > 1 ? RED : 0) + 160;
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    AST_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<T, BMW, NCT, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_lds = 160 * 1024;
-  }
-  const int gx = (g.Cd + BMW - 1) / BMW, gy = (g.ntaps * g.Cs + NCT * 16 - 1) / (NCT * 16);
-  // every workgroup adds its whole dW tile into the same few KB: same-address atomics serialise, so the workgroup count
-  // stays at about one per CU and the waves come from the pixel groups (sweep in profiles/r01 and r02)
-  const char* wt = getenv("AST_WGRAD_WG_TARGET");
-  const int wg_target = wt ? atoi(wt) : (PG > 1 ? 256 : ((long)g.N * g.Hm * g.Wm >= 1500000 ? 768 : 256));
-  const int gz = std::max(1, std::min((hp.ntiles + PG - 1) / PG, wg_target / (gx * gy)));
-  const unsigned dy_bytes = (unsigned)((size_t)g.N * g.Hm * g.Wm * g.Cd * sizeof(T));
-  const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
-  hipLaunchKernelGGL((wgrad_halo_kernel<T, BMW, NCT, PG>), dim3(gx, gy, gz), dim3(256 * PG), lds, s, (const T*)dy, (const T*)src, dw, g, hp,
-                     dy_bytes, src_bytes, g_wg_nrep, g_wg_rep_stride);
-  AST_CHECK_LAUNCH();
-  return 0;
-}
-
-template <typename T, int BMW, int NCT>
-int launch_wgrad_halo(const void* dy, const void* src, float* dw, const ast_gather_t& g, const WHaloPlan& hp, hipStream_t s) {
-  // pixel groups: as many as the LDS holds (<= 4), when every group gets several tiles
-  // (four groups need <= 128 VGPRs per thread; the kernel uses 130-200 and spills: 50 -> 105 us on the 32-channel layer)
-  const char* pe = getenv("AST_WGRAD_PG");
-  int pg = pe ? atoi(pe) : 2;
-  while (pg > 1 && (pg * hp.lds > 150 * 1024 || hp.ntiles < 256 * pg * 2)) pg >>= 1;
-  if (pg >= 4) return launch_wgrad_halo_pg<T, BMW, NCT, 4>(dy, src, dw, g, hp, s);
-  if (pg == 2) return launch_wgrad_halo_pg<T, BMW, NCT, 2>(dy, src, dw, g, hp, s);
-  return launch_wgrad_halo_pg<T, BMW, NCT, 1>(dy, src, dw, g, hp, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -1781,20 +1132,6 @@ int launch_igemm(const void* src, const void* wgt, const float* bias, void* dst,
   return launch_igemm_ut<T, BM, BN, WM, WN, KCH, D, KG, false>(src, wgt, bias, dst, g, M, flags, ws, p, s);
 }
 
-int check_gather(const ast_gather_t* g, const char* who) {
-  if (!g) AST_FAIL("%s: null geometry", who);
-  if (g->Cs <= 0 || g->Cd <= 0 || (g->Cs & 7) || (g->Cd & 7)) AST_FAIL("%s: channels must be positive multiples of 8 (Cs=%d Cd=%d)", who, g->Cs, g->Cd);
-  if (g->ntaps < 0 || g->ntaps > AST_MAX_TAPS || g->wtaps < 1 || g->wtaps > AST_MAX_TAPS) AST_FAIL("%s: bad tap counts %d/%d", who, g->ntaps, g->wtaps);
-  if (g->N <= 0 || g->Hm <= 0 || g->Wm <= 0 || g->Hs <= 0 || g->Ws <= 0 || g->Hd <= 0 || g->Wd <= 0) AST_FAIL("%s: empty tensor", who);
-  for (int t = 0; t < g->ntaps; ++t) if ((g->tap[t] >> 16) >= g->wtaps) AST_FAIL("%s: tap %d weight slice out of range", who, t);
-  // destination pixels must stay inside the tensor (a fault here can reset the GPU)
-  const long hmax = (long)(g->Hm - 1) * g->dsh + g->doh, wmax = (long)(g->Wm - 1) * g->dsw + g->dow;
-  if (g->doh < 0 || g->dow < 0 || hmax >= g->Hd || wmax >= g->Wd) AST_FAIL("%s: destination grid exceeds tensor (%ld,%ld) vs (%d,%d)", who, hmax, wmax, g->Hd, g->Wd);
-  if ((long)g->N * g->Hs * g->Ws * g->Cs * 4 >= (1L << 31) || (long)g->N * g->Hm * g->Wm >= (1L << 31) ||
-      (long)g->Cd * g->wtaps * g->Cs * 4 >= (1L << 31)) AST_FAIL("%s: tensor exceeds the 2 GiB buffer-addressing range", who);
-  return 0;
-}
-
 }  // namespace
 
 extern "C" long ast_igemm_ws_floats(const ast_gather_t* gp, int dtype) {
@@ -1890,41 +1227,4 @@ extern "C" int ast_igemm_bn(const void* src, const void* wgt, const float* bias,
 extern "C" int ast_igemm(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t* gp,
                          int dtype, int flags, float* ws, long ws_floats, void* stream) {
   return ast_igemm_bn(src, wgt, bias, dst, gp, dtype, flags & ~48, ws, ws_floats, nullptr, nullptr, nullptr, stream);
-}
-
-extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t* gp, int dtype, void* stream);
-extern "C" int ast_wgrad_rep(const void* dy, const void* src, float* dw, const ast_gather_t* gp, int dtype, int nrep, void* stream) {
-  if (nrep < 1 || nrep > 64 || !gp) AST_FAIL("ast_wgrad_rep: 1..64 replicas");
-  g_wg_nrep = nrep;
-  g_wg_rep_stride = (long)gp->Cd * gp->wtaps * gp->Cs;
-  const int rc = ast_wgrad(dy, src, dw, gp, dtype, stream);
-  g_wg_nrep = 1; g_wg_rep_stride = 0;
-  return rc;
-}
-
-extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t* gp, int dtype, void* stream) {
-  if (int rc = check_gather(gp, "ast_wgrad")) return rc;
-  if (!dy || !src || !dw) AST_FAIL("ast_wgrad: null pointer");
-  const ast_gather_t g = *gp;
-  if (g.ntaps == 0) return 0;
-  const int P = g.N * g.Hm * g.Wm;
-  if ((long)P * g.Cd * 4 >= (1L << 31)) AST_FAIL("ast_wgrad: dy exceeds the 2 GiB buffer-addressing range");
-  hipStream_t s = (hipStream_t)stream;
-  const int nct_all = (g.ntaps * g.Cs + 15) / 16;          // column tiles of the whole (tap, channel) space
-  const int bmw = g.Cd > 32 ? 64 : (g.Cd > 16 ? 32 : 16);
-  // all columns in one workgroup when the accumulators fit (<= 20 tiles x BMW/16 row tiles <= 20 per wave)
-  int nct;
-  if (bmw == 64) nct = nct_all <= 8 ? (nct_all <= 4 ? 4 : 8) : 12;
-  else nct = nct_all <= 4 ? 4 : (nct_all <= 8 ? 8 : (nct_all <= 12 ? 12 : 20));
-  WHaloPlan whp;
-  const bool halo = plan_wgrad_halo(g, dtype, nct, bmw, whp);
-#define AST_WG(B_, N_) do { if (halo) return launch_wgrad_halo<T, B_, N_>(dy, src, dw, g, whp, s); \
-                            return launch_wgrad<T, B_, N_>(dy, src, dw, g, P, s); } while (0)
-  AST_DISPATCH_T(dtype, {
-    if (bmw == 64) { if (nct == 4) AST_WG(64, 4); if (nct == 8) AST_WG(64, 8); AST_WG(64, 12); }
-    if (bmw == 32) { if (nct == 4) AST_WG(32, 4); if (nct == 8) AST_WG(32, 8); if (nct == 12) AST_WG(32, 12); AST_WG(32, 20); }
-    if (nct == 4) AST_WG(16, 4); if (nct == 8) AST_WG(16, 8); if (nct == 12) AST_WG(16, 12); AST_WG(16, 20);
-  });
-#undef AST_WG
-  return 0;
 }

@@ -18,7 +18,7 @@ def _run(pattern, n):
     return subprocess.run([sys.executable, TOOL, pattern, str(n)], capture_output=True, text=True, timeout=300)
 
 
-@pytest.mark.parametrize("pattern,n", [("seq", 32), ("fan", 24), ("keep", 24), ("nested", 16), ("bwd", 32), ("bwd_leaf", 32)])
+@pytest.mark.parametrize("pattern,n", [("seq", 32), ("fan", 24), ("keep", 24), ("bwd", 32), ("bwd_leaf", 32)])
 def test_joined_fork_patterns_capture_and_replay(pattern, n):
     r = _run(pattern, n)
     assert r.returncode == 0 and f"OK {pattern} {n}" in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-1500:])

@@ -217,6 +217,51 @@ def test_wgrad_replicas_sum_to_the_gradient(dtype, cin, cout, k, stride, H, W, N
         assert float(rep[1:].abs().max()) > 0 or Ho * Wo * N < 512          # the work really was spread
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,N", [
+    (64, 64, 3, 1, 30, 50, 4),       # one tap per 64-column tile, several pixel slices (atomic flush)
+    (32, 64, 3, 2, 37, 53, 3),       # two taps per column tile, stride 2, odd sizes, last column tile half empty
+    (64, 96, 3, 1, 17, 16, 2),       # partial second row tile (96 output channels)
+    (128, 192, 3, 1, 9, 19, 3),      # three row tiles x 18 column tiles
+    (256, 128, 3, 2, 10, 21, 2),
+    (512, 512, 3, 1, 5, 10, 2),      # deep layer: 576 tiles, one pixel slice (read-modify-write flush), 100 pixels
+    (40, 64, 1, 2, 22, 31, 2),       # 1x1 shortcut, 40 source channels (one partial column tile)
+    (8, 64, 3, 1, 12, 15, 1),        # 72 columns: 8-channel taps, nine taps over two tiles
+])
+def test_wgrad_tap_kernel(dtype, cin, cout, k, stride, H, W, N):
+    """The wave-autonomous tap-tile weight-gradient kernel (>= 64 output channels) against a plain PyTorch fp32 reference of the
+    same contraction and against the cooperative kernel it replaces (AST_WGRAD_TAP=0); a second launch into the same buffer
+    must ADD (the C-ABI contract: dw accumulates), with one and with many pixel slices."""
+    from ast_amd._lib import check, dcode, lib, ptr, stream
+    config.set_compute_dtype(dtype)
+    torch.manual_seed(11)
+    pad = 1 if k == 3 else 0
+    g, (Ho, Wo) = ops.gather_direct(N, H, W, cin, cout, k, stride, pad)
+    x = torch.randn(N, H, W, cin, device=DEV).to(dtype)
+    dy = torch.randn(N, Ho, Wo, cout, device=DEV).to(dtype)
+    # reference: dW[co][kh][kw][ci] = sum_p dy[p][co] * x[gather(p, kh, kw)][ci], in fp32 on the values as stored
+    xr = x.float().permute(0, 3, 1, 2).contiguous().requires_grad_(False)
+    w = torch.zeros(cout, cin, k, k, device=DEV, requires_grad=True)
+    F.conv2d(xr, w, stride=stride, padding=pad).backward(dy.float().permute(0, 3, 1, 2))
+    ref = w.grad.permute(0, 2, 3, 1).reshape(cout, k * k, cin)
+    outs = {}
+    for tap in (1, 0):
+        with _env(AST_WGRAD_TAP=tap):
+            dw = torch.zeros(cout, k * k, cin, device=DEV)
+            check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(dw), g, dcode(dtype), stream()), "ast_wgrad")
+            torch.cuda.synchronize()
+            outs[tap] = dw.clone()
+    tol = 2e-5 if dtype == torch.float32 else 2e-5         # both accumulate the stored values in f32: only the summation order differs
+    assert rel_err(outs[1], ref) < tol, rel_err(outs[1], ref)
+    assert rel_err(outs[1], outs[0]) < tol
+    for wgs in (1, 4096):                                  # one pixel slice (read-modify-write) / as many as the pixels allow (atomics)
+        with _env(AST_WGRAD_TAP=1, AST_WGRAD_TAP_WGS=wgs):
+            dw = outs[1].clone()
+            check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(dw), g, dcode(dtype), stream()), "ast_wgrad")
+            torch.cuda.synchronize()
+            assert rel_err(dw, 2.0 * ref) < tol, (wgs, rel_err(dw, 2.0 * ref))
+
+
 @pytest.mark.parametrize("R_out,R_in", [(2, 8), (16, 32), (64, 128), (3, 300)])
 def test_rowmix_fwd_bwd(R_out, R_in):
     """ast_rowmix (class prototypes / prototype gather / section means, style_encoder.py:243-253, losses.py:88,142) for

@@ -382,3 +382,36 @@ def test_lr_schedule_and_ramped_weights_replay_one_graph():
     assert abs(graph[9]["rec"] - const[9]["rec"]) > 1e-5 * abs(const[9]["rec"])
     w = trg.hyper.cpu()
     assert abs(float(w[train.H_LR_G]) - 2e-4) < 1e-9 and abs(float(w[train.H_W_ADV]) - 1.8) < 1e-6 and abs(float(w[train.H_LR_G + 1]) - 0.25) < 1e-7
+
+
+def test_graph_replay_survives_an_eval_pass_between_steps():
+    """train step (captured) -> eval-mode forward of the same modules (a validation pass: the weight banks build their eval
+    tables) -> train steps (REPLAYED).  The captured graph bakes the addresses of the banks' descriptor / tile tables in; an eval
+    build used to replace and free them, and the next replay read whatever the allocator had put there (a GPU memory fault in
+    bench.py's default run).  The tables are content-addressed and never freed now (layers.WeightBank._const_dev)."""
+    ast_amd.set_compute_dtype(torch.float32)
+    x, labels = train.synthetic_batch(4, 1, "cuda:0", seed=3)
+
+    def run(use_graph):
+        tr = train.Trainer(train.TrainConfig(use_graph=use_graph, dropout=False), seed=7)
+        hist = [{k: float(v) for k, v in tr.step(x, labels).items()}]
+        for m in (tr.style, tr.content, tr.decoder):
+            m.eval()
+        with torch.no_grad():
+            se, ce = tr.style(x, labels)
+            co = tr.content(x)
+            tr.decoder(co, ce[labels.to(x.device)].contiguous())
+        for m in (tr.style, tr.content, tr.decoder):
+            m.train()
+        junk = [torch.full((1 << 12,), 0x7fffffff, dtype=torch.int32, device="cuda:0") for _ in range(256)]   # land on whatever was freed
+        for _ in range(2):
+            hist.append({k: float(v) for k, v in tr.step(x, labels).items()})
+        torch.cuda.synchronize()
+        del junk
+        return hist, tr
+
+    eager, _ = run(False)
+    eager2, _ = run(False)
+    graph, trg = run(True)
+    assert len(trg._graphs) == 1
+    _assert_close_hist(graph, eager, _noise_tolerances(eager, eager2), "graph vs eager around an eval pass")

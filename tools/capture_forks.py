@@ -14,6 +14,10 @@ Patterns
   fan        N side streams forked, then all joined (events destroyed inside the capture)
   keep       as fan, but every Event object is kept alive until the capture has ended
   nested     side stream forks a second-level stream, joined back level by level
+  nested_pre    the same, but BOTH streams first join the capture from the origin stream (level-1 forks at the start)
+  nested_fresh  the same as nested with a fresh pair of streams per iteration
+  nested_direct second-level stream joined straight into the origin stream
+  nested_keep   nested with every Event object kept alive until the capture has ended
   tail       the side stream gets MORE work after its join event was recorded (an unjoined tail: what an autograd node that
              returns no gradient leaves behind when its backward runs on a side stream)
   unjoined   a forked stream is never joined (CUDA semantics: cudaErrorStreamCaptureUnjoined)
@@ -28,7 +32,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "audio-style-transfer_amd"))
 
-PATTERNS = ("seq", "fan", "keep", "nested", "tail", "unjoined", "bwd", "bwd_leaf")
+PATTERNS = ("seq", "fan", "keep", "nested", "nested_pre", "nested_fresh", "nested_direct", "nested_keep", "tail", "unjoined", "bwd", "bwd_leaf")
 
 
 def run_pattern(pattern, n):
@@ -44,7 +48,7 @@ def run_pattern(pattern, n):
     def scale(src, dst, s, st):
         check(lib().ast_scale(ptr(src), None, float(s), ptr(dst), src.numel(), 0, st.cuda_stream), "ast_scale")
 
-    sides = [torch.cuda.Stream(device=dev) for _ in range(max(2, n))]
+    sides = [torch.cuda.Stream(device=dev) for _ in range(max(2, 2 * n if pattern == "nested_fresh" else n))]
     # warm-up outside the capture (library load, allocator)
     for s in sides[:2]:
         s.wait_stream(torch.cuda.current_stream())
@@ -69,6 +73,7 @@ def run_pattern(pattern, n):
 
         @staticmethod
         def backward(ctx, dy):
+            dy = dy.contiguous()                        # (the gradient of sum() is an expanded 1-element tensor)
             main = torch.cuda.current_stream()
             side = sides[0]
             side.wait_stream(main)                      # leaf work (a "weight gradient") beside the data gradient
@@ -113,15 +118,26 @@ def run_pattern(pattern, n):
                 else:
                     main.wait_stream(sides[i])
             expect = [(i, i + 1.0) for i in range(n)]
-        elif pattern == "nested":
-            a, b = sides[0], sides[1]
+        elif pattern in ("nested", "nested_pre", "nested_fresh", "nested_direct", "nested_keep"):
+            def wait(dst, srcs):
+                if pattern == "nested_keep":
+                    e = torch.cuda.Event(); e.record(srcs); dst.wait_event(e); keep.append(e)
+                else:
+                    dst.wait_stream(srcs)
+            if pattern == "nested_pre":
+                for s in sides[:2]:
+                    s.wait_stream(main)            # both streams join the capture as children of the ORIGIN stream first
             for i in range(n):
-                a.wait_stream(main)
+                a, b = (sides[(2 * i) % len(sides)], sides[(2 * i + 1) % len(sides)]) if pattern == "nested_fresh" else (sides[0], sides[1])
+                wait(a, main)
                 scale(x, bufs[i], i + 1, a)
-                b.wait_stream(a)
+                wait(b, a)                         # second-level fork: b waits on an event recorded on a forked stream
                 scale(bufs[i], bufs[n], 1.0, b)
-                a.wait_stream(b)
-                main.wait_stream(a)
+                if pattern == "nested_direct":
+                    wait(main, b)
+                else:
+                    wait(a, b)
+                wait(main, a)
             expect = [(i, i + 1.0) for i in range(n)]
         elif pattern == "tail":
             s = sides[0]
