@@ -26,6 +26,61 @@ __device__ long long ast_wg_phase[4096 * 4];                // K-loop sub-phases
 // each wherever the address lives (tools/micro/l2atomic.hip: spreading the lines over channels or doing them at L2 level
 // changes nothing), so the flush of 85 workgroups per tile took 14 us of a 40 us launch (tools/wgrad_stamps.py); with 8
 // copies the chains are 11 deep.
+// The flush of a workgroup's dW tile.  D (MFMA accumulator) layout: lane (li, gq) holds rows 16 i + 4 gq + r, column 16 ct + li, so a
+// wave-instruction of atomics straight from the registers touched 4 rows x 64 B.  The memory-side atomic units take their full
+// rate only for 256 contiguous bytes (or 2 x 128 B) per wave-instruction (MI355X_MICROARCH.md "Global float atomics"; the
+// 4 x 64 B shape measured 0.87 TB/s of added bytes here against ~1.3 TB/s): the tile goes through LDS (free at this point) and
+// every wave adds whole 64-float row segments -- 64 consecutive (tap, channel) columns of one output channel = 256 contiguous
+// bytes when the source has >= 64 channels, two 128-byte runs for 32.  Ends with every thread of the (remaining) workgroup.
+template <int BMW, int NCT, int RT, int CTW, typename WtOf>
+__device__ __forceinline__ void flush_tile_rows(const f32x4 (&acc)[RT][CTW], float* tile, float* dw, const ast_gather_t& g, const int cd0,
+                                                const int col0, const int ncols, const int wave, const int lane, WtOf wt_of, const bool direct) {
+  constexpr int BNW = NCT * 16;
+  const int li = lane & 15, gq = lane >> 4;
+  if (direct) {                                      // A/B (AST_WGRAD_FLUSH_LDS=0): atomics straight from the accumulator registers
+#pragma unroll
+    for (int j = 0; j < CTW; ++j) {
+      const int ct = wave + 4 * j;
+      const int col = col0 + ct * 16 + li;
+      if (ct >= NCT || col >= ncols) continue;
+      const int t = col / g.Cs, c = col - t * g.Cs;
+      const int wtc = wt_of(t);
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cd = cd0 + i * 16 + gq * 4 + r;
+          if (cd < g.Cd) unsafeAtomicAdd(dw + ((size_t)cd * g.wtaps + wtc) * g.Cs + c, acc[i][j][r]);
+        }
+    }
+    return;
+  }
+  __syncthreads();                                   // the staging / reduction area is free
+#pragma unroll
+  for (int j = 0; j < CTW; ++j) {
+    const int ct = wave + 4 * j;
+    if (ct < NCT) {
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(i * 16 + gq * 4 + r) * BNW + ct * 16 + li] = acc[i][j][r];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int cc = 0; cc < BNW / 64; ++cc) {
+    const int col = col0 + cc * 64 + lane;
+    if (col >= ncols) continue;
+    const int t = col / g.Cs, c = col - t * g.Cs;
+    float* dcol = dw + (size_t)wt_of(t) * g.Cs + c;
+    for (int row = wave; row < BMW; row += 4) {
+      const int cd = cd0 + row;
+      if (cd < g.Cd) unsafeAtomicAdd(dcol + (size_t)cd * g.wtaps * g.Cs, tile[row * BNW + cc * 64 + lane]);
+    }
+  }
+}
+
+inline bool wg_flush_direct() { const char* e = getenv("AST_WGRAD_FLUSH_LDS"); return e && atoi(e) == 0; }
 static thread_local int g_wg_nrep = 1;
 static thread_local long g_wg_rep_stride = 0;
 template <typename T> struct WgradCfg;
@@ -54,7 +109,8 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
   extern __shared__ __attribute__((aligned(16))) unsigned char wl_all[];
   constexpr int GROUP_BYTES = (int)sizeof(T) * BKP * (PY + PX);
   constexpr int RED = PG > 1 ? RT * CTW * 256 * 16 : 0;                        // one group's partial tile in the final LDS reduction
-  constexpr int TAP_OFF = (PG * GROUP_BYTES > RED ? PG * GROUP_BYTES : RED);
+  constexpr int TILE = BMW * BNW * 4;                                          // the [row][column] f32 image of the flush
+  constexpr int TAP_OFF = std::max(std::max(PG * GROUP_BYTES, RED), TILE);
   const int pg = PG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
   unsigned char* wl = wl_all + pg * GROUP_BYTES;
   T* Ys = reinterpret_cast<T*>(wl);
@@ -238,24 +294,9 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
     if (pg > 0) return;
   }
   WG_STAMP(3);
-  dw += (size_t)(bz % nrep) * rep_stride;          // this pixel slice's gradient replica
-  // D[row = cd (gq*4+r)][col = column li]
-#pragma unroll
-  for (int j = 0; j < CTW; ++j) {
-    const int ct = wave + 4 * j;
-    const int col = col0 + ct * 16 + li;
-    if (ct >= NCT || col >= ncols) continue;
-    const int t = col / g.Cs, c = col - t * g.Cs;
-    int a, b, wtc;
-    decode_tap(taptab[t], a, b, wtc);
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cd = cd0 + i * 16 + gq * 4 + r;
-        if (cd < g.Cd) unsafeAtomicAdd(dw + ((size_t)cd * g.wtaps + wtc) * g.Cs + c, acc[i][j][r]);
-      }
-  }
+  dw += (size_t)(bz % (nrep < 0 ? -nrep : nrep)) * rep_stride;          // this pixel slice's gradient replica (sign of nrep: flush A/B switch)
+  flush_tile_rows<BMW, NCT, RT, CTW>(acc, reinterpret_cast<float*>(wl_all), dw, g, cd0, col0, ncols, wave, lane,
+                                     [&](int t) { return taptab[t] >> 16; }, nrep < 0);
 #ifdef AST_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the atomics have been acknowledged
 #endif
@@ -275,7 +316,7 @@ int launch_wgrad_pg(const void* dy, const void* src, float* dw, const ast_gather
   constexpr int BKP = WgradCfg<T>::BKP, PAD = WgradCfg<T>::PAD;
   constexpr int GROUP = (int)sizeof(T) * BKP * ((BMW + PAD) + (NCT * 16 + PAD));
   constexpr int RED = PG > 1 ? (BMW / 16) * ((NCT + 3) / 4) * 256 * 16 : 0;
-  constexpr int LDS = (PG * GROUP > RED ? PG * GROUP : RED) + 64;
+  constexpr int LDS = std::max(std::max(PG * GROUP, RED), BMW * NCT * 16 * 4) + 64;
   static bool attr_set = false;
   if (!attr_set) {
     AST_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<T, BMW, NCT, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -295,7 +336,7 @@ int launch_wgrad_pg(const void* dy, const void* src, float* dw, const ast_gather
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
   const int total = gx * gy * nsplit;
   hipLaunchKernelGGL((wgrad_kernel<T, BMW, NCT, PG>), dim3((total + 7) / 8 * 8), dim3(256 * PG), LDS, s, (const T*)dy, (const T*)src, dw, g, P, pps,
-                     dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm, gx, gy, nsplit, g_wg_nrep, g_wg_rep_stride);
+                     dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm, gx, gy, nsplit, wg_flush_direct() ? -g_wg_nrep : g_wg_nrep, g_wg_rep_stride);
   AST_CHECK_LAUNCH();
   return 0;
 }
@@ -347,7 +388,8 @@ __global__ __launch_bounds__(256 * PG) void wgrad_halo_kernel(const T* __restric
   T* Ys = reinterpret_cast<T*>(wl);
   T* Xp = Ys + MT * PY;                             // patch [PH*PW][Cs + pad]
   constexpr int RED = PG > 1 ? (BMW / 16) * ((NCT + 3) / 4) * 256 * 16 : 0;     // bytes of one group's partial tile in the final LDS reduction
-  int* taptab = reinterpret_cast<int*>(wl_all + max(PG * group_bytes, RED));   // behind both uses of the staging area
+  constexpr int TILE = BMW * NCT * 16 * 4;                                      // the [row][column] f32 image of the flush
+  int* taptab = reinterpret_cast<int*>(wl_all + max(max(PG * group_bytes, RED), TILE));   // behind every use of the staging area
 
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int cd0 = blockIdx.x * BMW, col0 = blockIdx.y * NCT * 16;
@@ -521,23 +563,9 @@ __global__ __launch_bounds__(256 * PG) void wgrad_halo_kernel(const T* __restric
     }
     if (pg > 0) return;
   }
-  // D[row = cd (gq*4+r)][col = column li]
-  dw += (size_t)(blockIdx.z % nrep) * rep_stride;      // this slice's gradient replica (see g_wg_nrep)
-#pragma unroll
-  for (int j = 0; j < CTW; ++j) {
-    const int ct = wave + 4 * j;
-    const int col = col0 + ct * 16 + li;
-    if (ct >= NCT || col >= ncols) continue;
-    const int t = col / g.Cs, c = col - t * g.Cs;
-    const int wtc = taptab[16 + t];
-#pragma unroll
-    for (int i = 0; i < RT; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cd = cd0 + i * 16 + gq * 4 + r;
-        if (cd < g.Cd) unsafeAtomicAdd(dw + ((size_t)cd * g.wtaps + wtc) * g.Cs + c, acc[i][j][r]);
-      }
-  }
+  dw += (size_t)(blockIdx.z % (nrep < 0 ? -nrep : nrep)) * rep_stride;      // this slice's gradient replica (see g_wg_nrep)
+  flush_tile_rows<BMW, NCT, RT, CTW>(acc, reinterpret_cast<float*>(wl_all), dw, g, cd0, col0, ncols, wave, lane,
+                                     [&](int t) { return taptab[16 + t]; }, nrep < 0);
 }
 
 bool plan_wgrad_halo(const ast_gather_t& g, int dtype, int nct, int bmw, WHaloPlan& hp) {
@@ -566,7 +594,7 @@ bool plan_wgrad_halo(const ast_gather_t& g, int dtype, int nct, int bmw, WHaloPl
 template <typename T, int BMW, int NCT, int PG>
 int launch_wgrad_halo_pg(const void* dy, const void* src, float* dw, const ast_gather_t& g, const WHaloPlan& hp, hipStream_t s) {
   constexpr int RED = (BMW / 16) * ((NCT + 3) / 4) * 256 * 16;          // bytes of one group's partial tile in the LDS reduction
-  const int lds = std::max(PG * hp.lds, PG > 1 ? RED : 0) + 160;
+  const int lds = std::max(std::max(PG * hp.lds, PG > 1 ? RED : 0), BMW * NCT * 16 * 4) + 160;
   static int attr_lds = 0;
   if (lds > attr_lds) {
     AST_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<T, BMW, NCT, PG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -581,7 +609,7 @@ int launch_wgrad_halo_pg(const void* dy, const void* src, float* dw, const ast_g
   const unsigned dy_bytes = (unsigned)((size_t)g.N * g.Hm * g.Wm * g.Cd * sizeof(T));
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
   hipLaunchKernelGGL((wgrad_halo_kernel<T, BMW, NCT, PG>), dim3(gx, gy, gz), dim3(256 * PG), lds, s, (const T*)dy, (const T*)src, dw, g, hp,
-                     dy_bytes, src_bytes, g_wg_nrep, g_wg_rep_stride);
+                     dy_bytes, src_bytes, wg_flush_direct() ? -g_wg_nrep : g_wg_nrep, g_wg_rep_stride);
   AST_CHECK_LAUNCH();
   return 0;
 }
@@ -850,8 +878,12 @@ extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_g
   if (bmw == 64) nct = nct_all <= 8 ? (nct_all <= 4 ? 4 : 8) : 12;
   else nct = nct_all <= 4 ? 4 : (nct_all <= 8 ? 8 : (nct_all <= 12 ? 12 : 20));
   // >= 64 output channels: the wave-autonomous tap-tile kernel (AST_WGRAD_TAP=0: the cooperative kernels below, for A/B)
+  // Opt-in (AST_WGRAD_TAP=1): measured SLOWER than the cooperative kernels below -- isolated 44.4 vs 39.4 us on the 64-channel
+  // layer, 71.8 vs 41.3 (256 channels), 67.2 vs 39.6 (512); only the stride-2 layers gain (24.9 vs 30.9) -- and the whole step
+  // 7.29 vs 6.2 ms: its nine tap tiles re-read every dy / source row nine times through L1 (398 MB per launch at ~9 TB/s: the
+  // fabric, not the MFMAs), and a workgroup takes a whole CU (128 KB of LDS) away from the other streams' kernels.  DESIGN 9.3.
   const char* te = getenv("AST_WGRAD_TAP");                  // read per call (host side only): tests toggle it at run time
-  const bool tap_on = !(te && atoi(te) == 0);
+  const bool tap_on = te && atoi(te) != 0;
   if (tap_on && g.Cd >= 64) { AST_DISPATCH_T(dtype, { return launch_wgrad_tap<T>(dy, src, dw, g, P, s); }); }
   WHaloPlan whp;
   const bool halo = plan_wgrad_halo(g, dtype, nct, bmw, whp);

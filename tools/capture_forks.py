@@ -18,6 +18,8 @@ Patterns
   nested_fresh  the same as nested with a fresh pair of streams per iteration
   nested_direct second-level stream joined straight into the origin stream
   nested_keep   nested with every Event object kept alive until the capture has ended
+  nested_via_main  the second-level stream is joined into the ORIGIN stream and the first-level stream then waits for the origin
+  sibling       two first-level streams; one waits for an event of the other, both join the origin
   tail       the side stream gets MORE work after its join event was recorded (an unjoined tail: what an autograd node that
              returns no gradient leaves behind when its backward runs on a side stream)
   unjoined   a forked stream is never joined (CUDA semantics: cudaErrorStreamCaptureUnjoined)
@@ -32,7 +34,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "audio-style-transfer_amd"))
 
-PATTERNS = ("seq", "fan", "keep", "nested", "nested_pre", "nested_fresh", "nested_direct", "nested_keep", "tail", "unjoined", "bwd", "bwd_leaf")
+PATTERNS = ("seq", "fan", "keep", "nested", "nested_pre", "nested_fresh", "nested_direct", "nested_keep", "nested_via_main", "sibling", "tail", "unjoined", "bwd", "bwd_leaf")
 
 
 def run_pattern(pattern, n):
@@ -139,6 +141,29 @@ def run_pattern(pattern, n):
                     wait(a, b)
                 wait(main, a)
             expect = [(i, i + 1.0) for i in range(n)]
+        elif pattern == "nested_via_main":
+            a, b = sides[0], sides[1]
+            for i in range(n):
+                a.wait_stream(main)
+                scale(x, bufs[i], i + 1, a)
+                b.wait_stream(a)
+                scale(bufs[i], bufs[n], 1.0, b)
+                main.wait_stream(b)                # join into the origin ...
+                a.wait_stream(main)                # ... and let the first-level stream wait for the origin
+                scale(bufs[n], bufs[n + 1], 1.0, a)
+                main.wait_stream(a)
+            expect = [(i, i + 1.0) for i in range(n)] + [(n + 1, float(n))]
+        elif pattern == "sibling":
+            a, b = sides[0], sides[1]
+            for i in range(n):
+                a.wait_stream(main)
+                b.wait_stream(main)
+                scale(x, bufs[i], i + 1, b)
+                a.wait_stream(b)                   # first-level stream waits on an event of its sibling
+                scale(bufs[i], bufs[n], 1.0, a)
+                main.wait_stream(a)
+                main.wait_stream(b)
+            expect = [(i, i + 1.0) for i in range(n)] + [(n, float(n))]
         elif pattern == "tail":
             s = sides[0]
             for i in range(n):
@@ -174,8 +199,9 @@ def run_pattern(pattern, n):
 def main():
     if len(sys.argv) >= 2 and sys.argv[1] == "--all":
         ns = [int(a) for a in sys.argv[2:]] or [4, 8, 16, 32]
+        pats = [p for p in os.environ.get("PATTERNS", ",".join(PATTERNS)).split(",") if p in PATTERNS]
         print(f"{'pattern':10s} " + " ".join(f"{'N=' + str(n):>12s}" for n in ns), flush=True)
-        for p in PATTERNS:
+        for p in pats:
             row = []
             for n in ns:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), p, str(n)], capture_output=True, text=True, timeout=300)
