@@ -62,6 +62,8 @@ _SIGS = {
     "ast_chan_stats": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "ast_norm_finalize": ([vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, f32, vp, vp, vp, vp, C.c_long, vp], i32),
     "ast_affine_act": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "ast_bn_apply_fwd": ([vp, vp, vp, vp, i32, C.c_long, vp, vp, vp, vp, vp, vp, f32, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "ast_bn_apply_bwd": ([vp, vp, vp, vp, vp, vp, i32, C.c_long, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "ast_norm_bwd_sums": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "ast_norm_bwd_sums_pre": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp], i32),
     "ast_norm_bwd_apply_pre": ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp], i32),
@@ -137,6 +139,9 @@ CALL_BYTES = {
     # norm backward apply: read dy, x (+ shortcut input), write dx (+ shortcut gradient)
     "ast_norm_bwd_apply_pre": lambda a: a[8] * a[9] * a[10] * _es(a[12]) * (3 + (2 if a[3] else 0)),
     "ast_norm_bwd_sums_pre": lambda a: a[5] * a[6] * a[7] * _es(a[9]) * (2 + (1 if a[3] else 0)),
+    # the same two passes with the statistics finalize folded in (ast_bn_apply_fwd / _bwd)
+    "ast_bn_apply_fwd": lambda a: a[18] * a[19] * a[20] * _es(a[23]) * (2 + (1 if a[1] else 0)),
+    "ast_bn_apply_bwd": lambda a: a[22] * a[23] * a[24] * _es(a[27]) * (3 + (2 if a[2] else 0)),
     "ast_chan_stats": lambda a: a[2] * a[3] * a[4] * _es(a[5]),
     # compute_comprehensive_loss: read output and target, write the gradient (f32)
     "ast_recon_loss": lambda a: 3 * 4 * a[3] * a[4] * 2 * a[5] * a[6],

@@ -39,3 +39,8 @@ fused_bn_bwd = _os.environ.get("AST_FUSED_BN_BWD", "1") != "0"
 
 # copies of the weight-gradient staging of small (pixel-rich) conv layers that ast_wgrad_rep spreads its atomics over
 wgrad_replicas = int(_os.environ.get("AST_WGRAD_REPLICAS", "8"))
+
+# BatchNorm / InstanceNorm statistics finalize folded into the apply passes (ast_bn_apply_fwd / _bwd): every workgroup of the
+# apply pass reduces the statistics table itself, so the ~78 single-wave finalize launches of a step disappear from its
+# dependency chain (AST_FUSED_FINALIZE=0 keeps norm_finalize + affine_act: the reference path for tests and A/B timing).
+fused_finalize = _os.environ.get("AST_FUSED_FINALIZE", "1") != "0"

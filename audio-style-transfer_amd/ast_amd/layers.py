@@ -294,7 +294,7 @@ def conv_with_stats(x, pw, k, stride, pad, training):
         N, H, W, Cs = x.shape
         g, _ = ops.gather_direct(N, H, W, Cs, pw.Cop, k, stride, pad)
         if ops.stats_fusable(g, ops.dcode(x.dtype)):
-            stats = ops._clean_scratch(ops.STAT_SLOTS * pw.Cop * 2, x.device, tag="bn-stats")
+            stats = ops.stat_table(ops.stat_slots(pw.Cop) * pw.Cop * 2, x.device)
     return ops.Conv2dFn.apply(x, pw.weight, pw, k, stride, pad, False, stats, _link_of(x)), stats
 
 
@@ -307,7 +307,7 @@ def convT_bn_act(x, pw, k, stride, pad, out_pad, bn: nn.BatchNorm2d, training, r
         Wo = (W - 1) * stride - 2 * pad + k + out_pad
         gs = ops.gathers_transposed(N, H, W, Cs, Ho, Wo, pw.Cop, k, stride, pad)
         if all(ops.stats_fusable(g, ops.dcode(x.dtype)) for g in gs):
-            stats = ops._clean_scratch(ops.STAT_SLOTS * pw.Cop * 2, x.device, tag="bn-stats")
+            stats = ops.stat_table(ops.stat_slots(pw.Cop) * pw.Cop * 2, x.device)
     y = ops.ConvT2dFn.apply(x, pw.weight, pw, k, stride, pad, out_pad, False, stats, _link_of(x))
     return _bn_apply(y, bn, training, relu, stats)
 
@@ -320,13 +320,13 @@ def res_head(x, p1, pd, stride, training):
         N, H, W, Cs = x.shape
         g, _ = ops.gather_direct(N, H, W, Cs, p1.Cop, 3, stride, 1)
         if ops.stats_fusable(g, ops.dcode(x.dtype)):
-            stats = ops._clean_scratch(ops.STAT_SLOTS * p1.Cop * 2, x.device, tag="bn-stats")
+            stats = ops.stat_table(ops.stat_slots(p1.Cop) * p1.Cop * 2, x.device)
     in_stats = None
     if training and config.fused_bn_stats:
         N, H, W, Cs = x.shape
         gd, _ = ops.gather_direct(N, H, W, Cs, pd.Cop, 1, stride, 0)
         if ops.in_stats_fusable(gd, ops.dcode(x.dtype)):
-            in_stats = ops._clean_scratch(N * pd.Cop * 2, x.device, tag="in-stats")
+            in_stats = ops.stat_table(N * pd.Cop * 2, x.device)
     c1, idn = ops.ResHeadFn.apply(x, p1.weight, pd.weight, p1, pd, stride, stats, in_stats)
     return c1, idn, stats, in_stats
 

@@ -111,6 +111,58 @@ def _ws_need(g, dt):
 STAT_SLOTS = 64
 
 
+def stat_slots(C):
+    """Rows of the statistics slot table a GEMM epilogue spreads its atomics over: 64, fewer for wide layers so that
+    C x slots <= 4096 (the consumer reduces the whole table in every workgroup: ast_bn_apply_fwd / _bwd)."""
+    s = STAT_SLOTS
+    while s > 8 and s * C > 4096:
+        s //= 2
+    return s
+
+
+def _slot_flags(slots):
+    return 0 if slots == 64 else ((slots.bit_length() - 1) << 8)
+
+
+class _StatArena:
+    """Zero-initialised f32 statistics tables ([slots][C][2] BatchNorm sums, [N][C][2] InstanceNorm sums, [..][C][3]
+    backward sums) for the GEMM epilogues and reduction passes to ADD into.  With the finalize folded into the apply passes
+    nobody can hand a table back clean (its readers are thousands of workgroups), so every table is a fresh region of one
+    arena, used once, and the arena is cleared by ONE memset at the start of a train step (stat_arena_reset: Trainer) -- a
+    region is never reused within a step, whatever stream its producer and consumer run on."""
+    CAP = 1 << 24                    # floats
+    by_device = {}
+
+
+def stat_table(n, device):
+    device = torch.device(device)
+    a = _StatArena.by_device.get(device)
+    if a is None:
+        a = _StatArena.by_device[device] = [torch.zeros(_StatArena.CAP, dtype=torch.float32, device=device), 0, 0]
+    n64 = (int(n) + 63) // 64 * 64
+    if a[1] + n64 > _StatArena.CAP:
+        # callers that never reset (modules used directly, outside a Trainer): clear everything once the arena is used up
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("statistics arena exhausted inside a hipGraph capture: call ops.stat_arena_reset() at the start of the step")
+        torch.cuda.synchronize(device)
+        a[0].zero_()
+        a[1] = 0
+    t = a[0][a[1]:a[1] + int(n)]
+    a[1] += n64
+    a[2] = max(a[2], a[1])
+    return t
+
+
+def stat_arena_reset(device):
+    """Clear every table handed out so far (one memset on the current stream) and start over.  Call where every stream that
+    used a table has been joined into the current one: the start of a train step."""
+    a = _StatArena.by_device.get(torch.device(device))
+    if a is None or a[2] == 0:
+        return
+    a[0][:a[2]].zero_()
+    a[1] = 0
+
+
 def stats_fusable(g, dt):
     """True when ast_igemm can add the BatchNorm statistics of its output in the epilogue (plans that do not split K)."""
     return _ws_need(g, dt) == 0
@@ -119,11 +171,11 @@ def stats_fusable(g, dt):
 class BNLink:
     """Hand-off between a BatchNorm2d(+ReLU) layer and the convolution that consumes its output: that convolution's
     data-gradient GEMM produces the layer's dy and can add the layer's backward sums in its epilogue (ast_igemm_bn)."""
-    __slots__ = ("x", "scale", "shift", "relu", "table", "filled")
+    __slots__ = ("x", "scale", "shift", "relu", "table", "filled", "slots")
 
     def __init__(self):
         self.x = self.scale = self.shift = self.table = None
-        self.relu, self.filled = True, False
+        self.relu, self.filled, self.slots = True, False, STAT_SLOTS
 
 
 def in_stats_fusable(g, dt):
@@ -139,14 +191,14 @@ def _igemm(src, wgt, bias, dst, g, flags=0, stats=None, bn=None, per_image=False
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     need = _ws_need(g, dcode(src.dtype))
-    if bn is not None:                          # [64][Cd][3] slots: BatchNorm-backward sums of the dy this GEMM produces
+    if bn is not None:                          # [slots][Cd][3]: BatchNorm-backward sums of the dy this GEMM produces
         assert need == 0 and flags == 0
-        check(lib().ast_igemm_bn(ptr(src), ptr(wgt), ptr(bias), ptr(dst), g, dcode(src.dtype), 16 | (0 if bn.relu else 32), ptr(bn.table),
+        check(lib().ast_igemm_bn(ptr(src), ptr(wgt), ptr(bias), ptr(dst), g, dcode(src.dtype), 16 | (0 if bn.relu else 32) | _slot_flags(bn.slots), ptr(bn.table),
                                  bn.table.numel(), ptr(bn.x), ptr(bn.scale), ptr(bn.shift), stream()), "ast_igemm_bn")
     else:
-        if stats is not None:                   # [64][Cd][2] slots filled by the epilogue (flags bit 3); never with split-K
+        if stats is not None:                   # [slots][Cd][2] table filled by the epilogue (flags bit 3); never with split-K
             assert need == 0 and flags == 0
-            ws, need, flags = stats, stats.numel(), (8 | 64 if per_image else 8)
+            ws, need, flags = stats, stats.numel(), (8 | 64 if per_image else 8 | _slot_flags(stats.numel() // (2 * g.Cd)))
         else:
             ws = _clean_scratch(need, src.device) if need > 0 else None    # persistent, handed back zeroed by the finish pass
             flags |= 4 if need > 0 else 0
@@ -264,7 +316,8 @@ def _bn_link_ready(link, geoms, x):
         return None
     if not all(stats_fusable(g, dcode(x.dtype)) for g in geoms):
         return None
-    link.table = _clean_scratch(STAT_SLOTS * x.shape[3] * 3, x.device, tag="bn-bwd")
+    link.slots = stat_slots(x.shape[3])
+    link.table = stat_table(link.slots * x.shape[3] * 3, x.device)
     return link
 
 
@@ -547,7 +600,7 @@ def _clean_scratch(n, device, tag=None):
 
 def _stats(x):
     N, H, W, C = x.shape
-    sums = _clean_scratch(N * C * 2, x.device)
+    sums = stat_table(N * C * 2, x.device)
     check(lib().ast_chan_stats(ptr(x), ptr(sums), N, H * W, C, dcode(x.dtype), 1, stream()), "ast_chan_stats")
     return sums
 
@@ -577,7 +630,7 @@ def _bn_batch_stats(x, gamma, beta, bn, stats=None):
     """(mean, rstd, scale, shift) of a training-mode BatchNorm2d over the local or (sync-BN) global batch.
     stats: the [64][C][2] slot table the producing conv's epilogue filled (then no statistics pass runs)."""
     N, H, W, C = x.shape
-    rows = STAT_SLOTS if stats is not None else N
+    rows = stats.numel() // (2 * C) if stats is not None else N
     sums = stats if stats is not None else _stats(x)
     pixels = N * H * W
     if _SyncBN.world > 1:
@@ -610,6 +663,23 @@ class BatchNormActFn(torch.autograd.Function):
         N, H, W, C = x.shape
         Creal = gamma.numel()
         ctx.link = None
+        ctx.fused = bool(training and config.fused_finalize and _SyncBN.world == 1)
+        if ctx.fused:
+            # statistics finalize + apply in ONE launch (ast_bn_apply_fwd): the table is reduced by every workgroup
+            tab = stats if stats is not None else _stats(x)
+            rows = tab.numel() // (2 * C)
+            out = torch.empty((4, C), dtype=torch.float32, device=x.device)
+            y = torch.empty_like(x)
+            check(lib().ast_bn_apply_fwd(ptr(x), None, ptr(y), ptr(tab), rows, N * H * W, None, ptr(gamma), ptr(beta), ptr(bn.running_mean),
+                                         ptr(bn.running_var), ptr(bn.num_batches_tracked), bn.eps, None, None, 0.0, ptr(out), None, N, H * W, C,
+                                         Creal, int(relu), dcode(x.dtype), stream()), "ast_bn_apply_fwd")
+            mean, rstd, scale, shift = out[0], out[1], out[2], out[3]
+            if link is not None:
+                link.x, link.scale, link.shift, link.relu = x, scale, shift, bool(relu)
+                ctx.link = link
+            ctx.save_for_backward(x, None, mean, rstd, scale, shift)
+            ctx.gamma, ctx.beta, ctx.relu, ctx.training = gamma, beta, relu, training
+            return y
         if training:
             mean, rstd, scale, shift = _bn_batch_stats(x, gamma, beta, bn, stats)
             if link is not None:                # the consumer conv's data gradient may add this layer's backward sums
@@ -635,11 +705,24 @@ class BatchNormActFn(torch.autograd.Function):
         N, H, W, C = x.shape
         gamma, beta = ctx.gamma, ctx.beta
         link = ctx.link
+        if ctx.fused:
+            if link is not None and link.filled:        # the data-gradient GEMM that produced dy added the sums to the slot table
+                link.filled = False
+                tab3, rows = link.table, link.slots
+            else:
+                tab3, rows = stat_table(N * C * 3, x.device), N
+                check(lib().ast_norm_bwd_sums_pre(ptr(dy), None, ptr(x), None, ptr(tab3), N, H * W, C, int(ctx.relu), dcode(x.dtype), 1,
+                                                  ptr(scale), ptr(shift), None, None, stream()), "ast_norm_bwd_sums")
+            dx = torch.empty_like(x)
+            check(lib().ast_bn_apply_bwd(ptr(dy), ptr(x), None, ptr(dx), None, ptr(tab3), rows, N * H * W, ptr(gamma), ptr(mean), ptr(rstd),
+                                         ptr(acc_grad(gamma)), ptr(acc_grad(beta)), None, None, None, None, None, ptr(scale), ptr(shift), None, None,
+                                         N, H * W, C, gamma.numel(), int(ctx.relu), dcode(x.dtype), stream()), "ast_bn_apply_bwd")
+            return dx, None, None, None, None, None, None, None
         k1 = torch.empty((C, 3), dtype=torch.float32, device=x.device)
         if link is not None and link.filled:
             # the data-gradient GEMM that produced dy already added (sum dz, sum dz*x) to the slot table: no pass over dy, x
             link.filled = False
-            check(lib().ast_norm_bwd_finalize_n(ptr(link.table), 1, STAT_SLOTS, 0, C, gamma.numel(), ptr(gamma), ptr(mean), ptr(rstd),
+            check(lib().ast_norm_bwd_finalize_n(ptr(link.table), 1, link.slots, 0, C, gamma.numel(), ptr(gamma), ptr(mean), ptr(rstd),
                                                 ptr(acc_grad(gamma)), ptr(acc_grad(beta)), ptr(k1), None, None, None, None, None, None,
                                                 N * H * W, stream()), "ast_norm_bwd_finalize")
             gsum = None
@@ -671,6 +754,20 @@ class ResTailFn(torch.autograd.Function):
     def forward(ctx, c2, ds, g1, b1, g2, b2, bn, inn, training, stats=None, in_stats=None):
         N, H, W, C = c2.shape
         Creal = g1.numel()
+        ctx.fused = bool(training and config.fused_finalize and _SyncBN.world == 1)
+        if ctx.fused:
+            tab1 = stats if stats is not None else _stats(c2)
+            tab2 = in_stats if in_stats is not None else _stats(ds)
+            rows1 = tab1.numel() // (2 * C)
+            out1 = torch.empty((4, C), dtype=torch.float32, device=c2.device)
+            out2 = torch.empty((4, N * C), dtype=torch.float32, device=c2.device)
+            y = torch.empty_like(c2)
+            check(lib().ast_bn_apply_fwd(ptr(c2), ptr(ds), ptr(y), ptr(tab1), rows1, N * H * W, ptr(tab2), ptr(g1), ptr(b1), ptr(bn.running_mean),
+                                         ptr(bn.running_var), ptr(bn.num_batches_tracked), bn.eps, ptr(g2), ptr(b2), inn.eps, ptr(out1), ptr(out2),
+                                         N, H * W, C, Creal, 1, dcode(c2.dtype), stream()), "ast_bn_apply_fwd")
+            ctx.save_for_backward(c2, ds, None, out1[0], out1[1], out2[0], out2[1], out1[2], out1[3], out2[2], out2[3])
+            ctx.params, ctx.training = (g1, b1, g2, b2), training
+            return y
         if training:
             m1, r1, s1, f1 = _bn_batch_stats(c2, g1, b1, bn, stats)
         else:
@@ -696,6 +793,15 @@ class ResTailFn(torch.autograd.Function):
         dy = dy.contiguous()
         N, H, W, C = c2.shape
         dev = c2.device
+        if ctx.fused:
+            tab3 = stat_table(N * C * 3, dev)
+            check(lib().ast_norm_bwd_sums_pre(ptr(dy), None, ptr(c2), ptr(ds), ptr(tab3), N, H * W, C, 1, dcode(c2.dtype), 1,
+                                              ptr(s1), ptr(f1), ptr(s2), ptr(f2), stream()), "ast_norm_bwd_sums")
+            dc2, dds = torch.empty_like(c2), torch.empty_like(ds)
+            check(lib().ast_bn_apply_bwd(ptr(dy), ptr(c2), ptr(ds), ptr(dc2), ptr(dds), ptr(tab3), N, N * H * W, ptr(g1), ptr(m1), ptr(r1),
+                                         ptr(acc_grad(g1)), ptr(acc_grad(b1)), ptr(g2), ptr(m2), ptr(r2), ptr(acc_grad(g2)), ptr(acc_grad(b2)),
+                                         ptr(s1), ptr(f1), ptr(s2), ptr(f2), N, H * W, C, g1.numel(), 1, dcode(c2.dtype), stream()), "ast_bn_apply_bwd")
+            return dc2, dds, None, None, None, None, None, None, None, None, None
         sums3 = _clean_scratch(N * C * 3, dev)
         coef = (ptr(s1), ptr(f1), ptr(s2), ptr(f2)) if pre else (None, None, None, None)
         check(lib().ast_norm_bwd_sums_pre(ptr(dy), ptr(y), ptr(c2), ptr(ds), ptr(sums3), N, H * W, C, 1, dcode(c2.dtype),

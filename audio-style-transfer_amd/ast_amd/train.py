@@ -348,6 +348,7 @@ class Trainer:
 
     # The step as three segments; the data-parallel gradient all-reduces sit between them.
     def _seg_a(self, x, labels_host):
+        ops.stat_arena_reset(self.device)            # every BatchNorm / InstanceNorm statistics table of the step: ONE memset
         self._run_frontend(x)
         self._carry = self._forward_backward(x, labels_host)          # zero grads, encoders fwd, D-phase fwd+bwd
 
@@ -381,6 +382,7 @@ class Trainer:
         decoder forward and the D-independent losses; the streams join before the generator's adversarial term, which
         needs the updated discriminator (same arithmetic and order of updates as _step_body)."""
         c = self.cfg
+        ops.stat_arena_reset(self.device)            # every BatchNorm / InstanceNorm statistics table of the step: ONE memset
         held = self._prepare_beside_frontend()
         try:
             return self._step_overlapped_held(x, labels_host)

@@ -107,6 +107,10 @@ __device__ __forceinline__ void epi_pixel(const EpiCtx<T>& ec, const ast_gather_
 // `red` (LDS, (TN+1)/2 * 256 floats, free at this point up to a barrier) and wave 0 alone issues the atomics.  Same-address
 // f32 atomics serialise, and a 0.7 M-pixel layer has 5 382 tiles: per-wave atomics put 336 adds behind each other on every
 // address of the 64-slot table, 1 345 on a per-image table.  Every thread of the workgroup must arrive.
+// flags bits 8-11: log2 of the number of statistics slots (0 = 64): wide layers take fewer slots so that the consumer, which
+// reduces the table itself (ast_bn_apply_fwd / _bwd), reads at most C x slots = 4096 entries
+__host__ __device__ __forceinline__ int stat_slot_mask(const int flags) { const int l = (flags >> 8) & 15; return l ? (1 << l) - 1 : 63; }
+
 template <int TN>
 __device__ __forceinline__ void epi_flush(float* ws, const bool bstats, const int Cd, float (&st1)[TN][4], float (&st2)[TN][4], const int tix,
                                           const int cbase, const int fr, const int fq, float* red = nullptr) {
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_kernel(const T* __restrict__ s
   }
   // WN == 1: the four waves split the tile's pixels and share its channels -> one atomic per value per WORKGROUP
   float* const red = (KG == 1 && WN == 1) ? reinterpret_cast<float*>(lds_all) : nullptr;
-  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, per_image ? ~img : tix, bn0 + wn * WTN, fr, fq, red);
+  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, per_image ? ~img : (tix & stat_slot_mask(flags)), bn0 + wn * WTN, fr, fq, red);
 }
 
 // ---- narrow layers: operands straight from L1/L2 into MFMA fragments, no LDS ----------------------------------------
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(const T* __restrict__
     if (j + 1 < jt) compute(j + 1, xb, pb);
   }
   __shared__ float red[(TN + 1) / 2 * 256];                  // the four waves split the pixels: one atomic per value per workgroup
-  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, tix, bn0, fr, fq, red);
+  if (stats || bstats) epi_flush<T, TN>(ec, g, st1, st2, tix & stat_slot_mask(flags), bn0, fr, fq, red);
 }
 
 template <typename T>
@@ -885,8 +889,8 @@ __global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(cons
   else if (bstats) run(std::integral_constant<int, 2>{});
   else run(std::integral_constant<int, 0>{});
   PC_STAMP(4);
-  if (stats || bstats) epi_flush<TN>(ws, bstats, g.Cd, st1, st2, (flags & 64) ? ~n : tix, bn0, fr, fq,
-                                       (flags & 64) ? reinterpret_cast<float*>(pl) : nullptr);   // per-image tables only: with 64 slots the per-wave atomics are as fast (and one barrier pair cheaper)      // bit 6: per-image slots (tiles never straddle images)
+  if (stats || bstats) epi_flush<TN>(ws, bstats, g.Cd, st1, st2, (flags & 64) ? ~n : (tix & stat_slot_mask(flags)), bn0, fr, fq,
+                                       ((flags & 64) || stat_slot_mask(flags) < 63) ? reinterpret_cast<float*>(pl) : nullptr);   // per-image tables only: with 64 slots the per-wave atomics are as fast (and one barrier pair cheaper)      // bit 6: per-image slots (tiles never straddle images)
   PC_STAMP(5); PC_STAMP(6);
 }
 #ifdef AST_STAMPS
@@ -1175,9 +1179,9 @@ extern "C" int ast_igemm_bn(const void* src, const void* wgt, const float* bias,
   {
     PconvPlan pp; int slb = 0, tn = 0;
     if (plan_pconv(g, dtype, pp, slb, tn)) {
-      if ((flags & 16) && ((flags & 11) || !ws || ws_floats < 64L * g.Cd * 3 || !bn_x || !bn_scale || !bn_shift))
+      if ((flags & 16) && ((flags & 11) || !ws || ws_floats < (stat_slot_mask(flags) + 1L) * g.Cd * 3 || !bn_x || !bn_scale || !bn_shift))
         AST_FAIL("ast_igemm: fused BatchNorm-backward sums need plain stores, a zeroed [64][Cd][3] table and the layer's x / scale / shift");
-      if ((flags & 8) && ((flags & 3) || !ws || ws_floats < ((flags & 64) ? (long)g.N : 64L) * g.Cd * 2)) AST_FAIL("ast_igemm: fused channel statistics need plain stores and a zeroed [64][Cd][2] (per image: [N][Cd][2]) table");
+      if ((flags & 8) && ((flags & 3) || !ws || ws_floats < ((flags & 64) ? (long)g.N : stat_slot_mask(flags) + 1L) * g.Cd * 2)) AST_FAIL("ast_igemm: fused channel statistics need plain stores and a zeroed [64][Cd][2] (per image: [N][Cd][2]) table");
 #define AST_PC(S_, M_, N_) return launch_pconv<T, S_, M_, N_>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s)
       AST_DISPATCH_T(dtype, {
         if (slb == 128 && pp.tm == 2) { if (tn == 4) AST_PC(128, 2, 4); AST_PC(128, 2, 2); }
@@ -1195,9 +1199,9 @@ extern "C" int ast_igemm_bn(const void* src, const void* wgt, const float* bias,
     if (flags & (8 | 16)) AST_FAIL("ast_igemm: fused statistics (flags 8 / 16) are not available for a split-K plan (ast_igemm_ws_floats > 0)");
     if (!ws || ws_floats < (long)M * g.Cd) AST_FAIL("ast_igemm: this plan splits K and needs a workspace of %ld floats (ast_igemm_ws_floats), got %ld", (long)M * g.Cd, ws ? ws_floats : 0L);
   }
-  if ((flags & 16) && ((flags & 11) || !ws || ws_floats < 64L * g.Cd * 3 || !bn_x || !bn_scale || !bn_shift))
+  if ((flags & 16) && ((flags & 11) || !ws || ws_floats < (stat_slot_mask(flags) + 1L) * g.Cd * 3 || !bn_x || !bn_scale || !bn_shift))
     AST_FAIL("ast_igemm: fused BatchNorm-backward sums need plain stores, a zeroed [64][Cd][3] table and the layer's x / scale / shift");
-  if ((flags & 8) && !(flags & 64) && ((flags & 3) || !ws || ws_floats < 64L * g.Cd * 2))
+  if ((flags & 8) && !(flags & 64) && ((flags & 3) || !ws || ws_floats < (stat_slot_mask(flags) + 1L) * g.Cd * 2))
     AST_FAIL("ast_igemm: fused channel statistics need plain stores and a zeroed [64][Cd][2] table");
   if (flags & 64) {
     if (!(flags & 8) || (flags & 3) || p.nsplit > 1 || direct_ok(g, p, dtype)) AST_FAIL("ast_igemm: per-image statistics (flag 64) need flag 8, plain stores and the gathered kernel (ast_igemm_plan: kch > 0, no split)");

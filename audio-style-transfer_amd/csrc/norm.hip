@@ -315,6 +315,225 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
   }
 }
 
+// ---- statistics finalize folded into the apply passes ---------------------------------------------------------------------
+// The per-channel coefficients of a BatchNorm / InstanceNorm layer used to come from their own launches (norm_finalize,
+// norm_bwd_finalize): 38 + 40 single-wave kernels of ~5 us per step that do nothing but sit between a GEMM and the pass that
+// needs their 4 x C floats -- pure dependency latency on the step's longest chain (0.7 ms of the step is node
+// dispatch).  Here every workgroup of the APPLY pass reduces the statistics table itself (C x slots x 2-3 floats from L2, at
+// most 32 KB: the host keeps C x slots <= 4096) into LDS before its pixel loop; workgroup (0, 0) also writes the layer's
+// outputs (mean / rstd / scale / shift for the backward pass, running statistics, gamma / beta gradients).  Nobody may clear
+// the table (other workgroups are still reading it): the tables live in a per-step arena that ONE memset clears (ops.stat_table).
+//   coef (LDS): [0,C) scale1, [C,2C) shift1, [2C,3C) scale2 of image n, [3C,4C) shift2 of image n, then reduction scratch
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ y,
+                                                            const float* __restrict__ tab1, const int rows1, const float count1,
+                                                            const float* __restrict__ tab2, const float* __restrict__ gamma1,
+                                                            const float* __restrict__ beta1, float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, int64_t* __restrict__ nbt, const float eps1,
+                                                            const float* __restrict__ gamma2, const float* __restrict__ beta2, const float eps2,
+                                                            float* __restrict__ out1, float* __restrict__ out2, const int N, const int HW,
+                                                            const int C, const int Creal, const int relu) {
+  extern __shared__ float coef[];
+  const int tid = threadIdx.x, n = blockIdx.y;
+  const bool lead = blockIdx.x == 0 && n == 0;
+  const int nparts = max(1, min(rows1, 256 / min(C, 256)));          // threads per channel in the slot reduction
+  float* part = coef + 4 * C;
+  for (int idx = tid; idx < C * nparts; idx += 256) {
+    const int c = idx % C, pt = idx / C;
+    float s0 = 0.f, s1 = 0.f;
+    for (int q = pt; q < rows1; q += nparts) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(tab1 + ((size_t)q * C + c) * 2);
+      s0 += v[0]; s1 += v[1];
+    }
+    part[(pt * C + c) * 2] = s0; part[(pt * C + c) * 2 + 1] = s1;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int pt = 0; pt < nparts; ++pt) { s0 += part[(pt * C + c) * 2]; s1 += part[(pt * C + c) * 2 + 1]; }
+    const double cnt = (double)count1;
+    const double md = (double)s0 / cnt, vd = fmax((double)s1 / cnt - md * md, 0.0);
+    const float m = (float)md, rs = rsqrtf((float)vd + eps1);
+    const bool real = c < Creal;
+    const float g = real ? gamma1[c] : 0.f, b = real ? beta1[c] : 0.f;
+    const float sc = g * rs, sf = b - m * g * rs;
+    coef[c] = sc; coef[C + c] = sf;
+    if (lead) {
+      out1[c] = m; out1[C + c] = rs; out1[2 * C + c] = sc; out1[3 * C + c] = sf;
+      if (running_mean && real) {                                      // momentum 0.1, unbiased variance (nn.BatchNorm2d)
+        running_mean[c] = 0.9f * running_mean[c] + 0.1f * m;
+        running_var[c] = 0.9f * running_var[c] + 0.1f * (float)(vd * cnt / fmax(cnt - 1.0, 1.0));
+      }
+    }
+    if (r) {                                                           // InstanceNorm2d of the second input, image n
+      const float cntf = (float)HW;
+      const float m2 = tab2[((size_t)n * C + c) * 2] / cntf;
+      const float v2 = fmaxf(tab2[((size_t)n * C + c) * 2 + 1] / cntf - m2 * m2, 0.f);
+      const float r2 = rsqrtf(v2 + eps2);
+      const float g2 = real ? gamma2[c] : 0.f, b2 = real ? beta2[c] : 0.f;
+      coef[2 * C + c] = g2 * r2; coef[3 * C + c] = b2 - m2 * g2 * r2;
+      if (blockIdx.x == 0) {
+        const size_t o = (size_t)n * C + c, NC = (size_t)N * C;
+        out2[o] = m2; out2[NC + o] = r2; out2[2 * NC + o] = g2 * r2; out2[3 * NC + o] = b2 - m2 * g2 * r2;
+      }
+    }
+  }
+  if (lead && tid == 0 && nbt) nbt[0] += 1;                            // BatchNorm2d.num_batches_tracked
+  __syncthreads();
+
+  const int U = C >> 3;
+  const size_t per_img = (size_t)HW * U, base = (size_t)n * per_img;
+  const size_t stride = (size_t)gridDim.x * 256;
+  const bool hoist = (256 % U) == 0;
+  float sc[8], sf[8], sc2[8], sf2[8];
+  auto load_coef = [&](int u) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = coef[u * 8 + k]; sf[k] = coef[C + u * 8 + k]; }
+    if (r) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { sc2[k] = coef[2 * C + u * 8 + k]; sf2[k] = coef[3 * C + u * 8 + k]; }
+    }
+  };
+  const size_t j0 = (size_t)blockIdx.x * 256 + tid;
+  if (hoist) load_coef((int)(j0 % U));
+  for (size_t j = j0; j < per_img; j += stride) {
+    if (!hoist) load_coef((int)(j % U));
+    const size_t i = base + j;
+    float v[8];
+    U8<T>::load(x + i * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __builtin_fmaf(v[k], sc[k], sf[k]);
+    if (r) {
+      float w[8];
+      U8<T>::load(r + i * 8, w);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += __builtin_fmaf(w[k], sc2[k], sf2[k]);
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    U8<T>::store(y + i * 8, v);
+  }
+}
+
+// Backward twin: k1[c][3] (batch branch, from all rows of tab3) and k2[c][3] (instance branch of image n, from row n) are
+// formed in LDS by every workgroup; workgroup (0, 0) adds the gamma / beta gradients.  tab3[row][c] = {sum dz, sum dz x, sum dz r};
+// rows = statistics slots (filled by the data-gradient GEMM's epilogue, count = pixels) or images (a reduction pass).
+//   kc (LDS): [0,3C) k1, [3C,6C) k2, then reduction scratch
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ r,
+                                                            T* __restrict__ dx, T* __restrict__ dr, const float* __restrict__ tab3,
+                                                            const int rows, const float count, const float* __restrict__ gamma1,
+                                                            const float* __restrict__ mean1, const float* __restrict__ rstd1,
+                                                            float* __restrict__ dgamma1, float* __restrict__ dbeta1,
+                                                            const float* __restrict__ gamma2, const float* __restrict__ mean2,
+                                                            const float* __restrict__ rstd2, float* __restrict__ dgamma2,
+                                                            float* __restrict__ dbeta2, const float* __restrict__ sc1, const float* __restrict__ sf1,
+                                                            const float* __restrict__ sc2, const float* __restrict__ sf2, const int N, const int HW,
+                                                            const int C, const int Creal, const int relu) {
+  extern __shared__ float kc[];
+  const int tid = threadIdx.x, n = blockIdx.y;
+  const bool lead = blockIdx.x == 0 && n == 0;
+  const int nparts = max(1, min(rows, 256 / min(C, 256)));
+  float* part = kc + 6 * C;
+  for (int idx = tid; idx < C * nparts; idx += 256) {
+    const int c = idx % C, pt = idx / C;
+    float s0 = 0.f, s1 = 0.f;
+    for (int q = pt; q < rows; q += nparts) {
+      const float* t3 = tab3 + ((size_t)q * C + c) * 3;
+      s0 += t3[0]; s1 += t3[1];
+    }
+    part[(pt * C + c) * 2] = s0; part[(pt * C + c) * 2 + 1] = s1;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int pt = 0; pt < nparts; ++pt) { s0 += part[(pt * C + c) * 2]; s1 += part[(pt * C + c) * 2 + 1]; }
+    const bool real = c < Creal;
+    if (real) {
+      const double P = (double)count, g = gamma1[c], m = mean1[c], rs = rstd1[c], S0 = s0, S1 = s1;
+      const double Q = rs * (S1 - m * S0);
+      kc[c * 3 + 0] = (float)(g * rs);
+      kc[c * 3 + 1] = (float)(-g * rs * rs * Q / P);
+      kc[c * 3 + 2] = (float)(-g * rs * S0 / P + g * rs * rs * m * Q / P);
+      if (lead) { if (dgamma1) dgamma1[c] += (float)Q; if (dbeta1) dbeta1[c] += (float)S0; }
+    } else { kc[c * 3] = kc[c * 3 + 1] = kc[c * 3 + 2] = 0.f; }
+    if (dr) {                                                          // instance branch: image n (tab3 rows are images here)
+      if (real) {
+        const size_t i = (size_t)n * C + c;
+        const double P = (double)HW, g = gamma2[c], m = mean2[i], rs = rstd2[i], T0 = tab3[i * 3], T2 = tab3[i * 3 + 2];
+        const double Q = rs * (T2 - m * T0);
+        kc[3 * C + c * 3 + 0] = (float)(g * rs);
+        kc[3 * C + c * 3 + 1] = (float)(-g * rs * rs * Q / P);
+        kc[3 * C + c * 3 + 2] = (float)(-g * rs * T0 / P + g * rs * rs * m * Q / P);
+        if (lead) {                                                    // gamma2 / beta2 gradients: sums over the images, in a fixed order
+          float dg = 0.f, db = 0.f;
+          for (int q = 0; q < N; ++q) {
+            const size_t iq = (size_t)q * C + c;
+            const float t0 = tab3[iq * 3], t2 = tab3[iq * 3 + 2];
+            dg += (float)((double)rstd2[iq] * ((double)t2 - (double)mean2[iq] * (double)t0));
+            db += t0;
+          }
+          if (dgamma2) dgamma2[c] += dg;
+          if (dbeta2) dbeta2[c] += db;
+        }
+      } else { kc[3 * C + c * 3] = kc[3 * C + c * 3 + 1] = kc[3 * C + c * 3 + 2] = 0.f; }
+    }
+  }
+  __syncthreads();
+
+  const int U = C >> 3;
+  const size_t per_img = (size_t)HW * U, base = (size_t)n * per_img;
+  const size_t stride = (size_t)gridDim.x * 256;
+  const bool hoist = (256 % U) == 0;
+  const bool remask = relu != 0;                   // mask recomputed from the pre-activation fma(x, sc1, sf1) [+ fma(r, sc2[n], sf2[n])]
+  float a1[8], b1[8], a2[8], b2[8], ka[8][3], kb[8][3];
+  auto load_coef = [&](int u) __attribute__((always_inline)) {
+    if (remask) {
+      U8<float>::load(sc1 + u * 8, a1);
+      U8<float>::load(sf1 + u * 8, b1);
+      if (r) {
+        U8<float>::load(sc2 + (size_t)n * C + u * 8, a2);
+        U8<float>::load(sf2 + (size_t)n * C + u * 8, b2);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { ka[k][q] = kc[(u * 8 + k) * 3 + q]; if (dr) kb[k][q] = kc[3 * C + (u * 8 + k) * 3 + q]; }
+  };
+  const size_t j0 = (size_t)blockIdx.x * 256 + tid;
+  if (hoist) load_coef((int)(j0 % U));
+  for (size_t j = j0; j < per_img; j += stride) {
+    if (!hoist) load_coef((int)(j % U));
+    const size_t i = base + j;
+    float dz[8], v[8], o[8], vr[8];
+    U8<T>::load(dy + i * 8, dz);
+    U8<T>::load(x + i * 8, v);
+    if (r) U8<T>::load(r + i * 8, vr);
+    if (remask) {
+      float pre[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pre[k] = __builtin_fmaf(v[k], a1[k], b1[k]);
+      if (r) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pre[k] += __builtin_fmaf(vr[k], a2[k], b2[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dz[k] = pre[k] > 0.f ? dz[k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = ka[k][0] * dz[k] + ka[k][1] * v[k] + ka[k][2];
+    U8<T>::store(dx + i * 8, o);
+    if (dr) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = kb[k][0] * dz[k] + kb[k][1] * vr[k] + kb[k][2];
+      U8<T>::store(dr + i * 8, o);
+    }
+  }
+}
+
 // ---- LayerNorm over the last dim (rows x D), one wave per row, f32 --------------
 __global__ void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
@@ -624,6 +843,44 @@ extern "C" int ast_norm_bwd_apply(const void* dy, const void* y, const void* x, 
                                   const float* k2, void* dx, void* dr, int N, int HW, int C, int relu, int dtype,
                                   void* stream) {
   return ast_norm_bwd_apply_pre(dy, y, x, r, k1, k2, dx, dr, N, HW, C, relu, dtype, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int ast_bn_apply_fwd(const void* x, const void* r, void* y, const float* tab1, int rows1, long count1, const float* tab2,
+                               const float* gamma1, const float* beta1, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               float eps1, const float* gamma2, const float* beta2, float eps2, float* out1, float* out2, int N, int HW, int C,
+                               int Creal, int relu, int dtype, void* stream) {
+  if (!x || !y || !tab1 || !gamma1 || !beta1 || !out1 || rows1 < 1 || count1 < 1 || N < 1 || HW < 1 || C < 8 || (C & 7) || C > 2048 || Creal > C)
+    AST_FAIL("ast_bn_apply_fwd: bad args (rows %d count %ld N %d HW %d C %d)", rows1, count1, N, HW, C);
+  if (r && (!tab2 || !gamma2 || !beta2 || !out2)) AST_FAIL("ast_bn_apply_fwd: the second (InstanceNorm) input needs its table, gamma / beta and out2");
+  if ((long)rows1 * C > 65536) AST_FAIL("ast_bn_apply_fwd: statistics table too large for the in-kernel reduction (rows %d x C %d)", rows1, C);
+  const int nparts = std::max(1, std::min(rows1, 256 / std::min(C, 256)));
+  const size_t lds = sizeof(float) * (size_t)(4 * C + 2 * C * nparts);
+  const dim3 grid(std::max(1, std::min<int>((int)(((size_t)HW * (C >> 3) + 255) / 256), std::max(1, elem_blocks() / N))), N);
+  AST_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_fwd_kernel<T>), grid, dim3(256), lds, (hipStream_t)stream, (const T*)x, (const T*)r, (T*)y, tab1,
+                                            rows1, (float)count1, tab2, gamma1, beta1, running_mean, running_var, num_batches_tracked, eps1, gamma2,
+                                            beta2, eps2, out1, out2, N, HW, C, Creal, relu));
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ast_bn_apply_bwd(const void* dy, const void* x, const void* r, void* dx, void* dr, const float* tab3, int rows, long count,
+                               const float* gamma1, const float* mean1, const float* rstd1, float* dgamma1, float* dbeta1,
+                               const float* gamma2, const float* mean2, const float* rstd2, float* dgamma2, float* dbeta2,
+                               const float* scale1, const float* shift1, const float* scale2, const float* shift2, int N, int HW, int C,
+                               int Creal, int relu, int dtype, void* stream) {
+  if (!dy || !x || !dx || !tab3 || !gamma1 || !mean1 || !rstd1 || rows < 1 || count < 1 || N < 1 || HW < 1 || C < 8 || (C & 7) || C > 2048 || Creal > C)
+    AST_FAIL("ast_bn_apply_bwd: bad args (rows %d count %ld N %d HW %d C %d)", rows, count, N, HW, C);
+  if (dr && (!r || !gamma2 || !mean2 || !rstd2 || rows != N)) AST_FAIL("ast_bn_apply_bwd: the instance branch needs r, gamma2 / mean2 / rstd2 and a per-image table (rows == N)");
+  if (relu && (!scale1 || !shift1 || (r && (!scale2 || !shift2)))) AST_FAIL("ast_bn_apply_bwd: the ReLU mask is recomputed from the pre-activation: scale / shift required");
+  if ((long)rows * C > 65536) AST_FAIL("ast_bn_apply_bwd: statistics table too large for the in-kernel reduction (rows %d x C %d)", rows, C);
+  const int nparts = std::max(1, std::min(rows, 256 / std::min(C, 256)));
+  const size_t lds = sizeof(float) * (size_t)(6 * C + 2 * C * nparts);
+  const dim3 grid(std::max(1, std::min<int>((int)(((size_t)HW * (C >> 3) + 255) / 256), std::max(1, elem_blocks() / N))), N);
+  AST_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_apply_bwd_kernel<T>), grid, dim3(256), lds, (hipStream_t)stream, (const T*)dy, (const T*)x, (const T*)r,
+                                            (T*)dx, (T*)dr, tab3, rows, (float)count, gamma1, mean1, rstd1, dgamma1, dbeta1, gamma2, mean2, rstd2,
+                                            dgamma2, dbeta2, scale1, shift1, scale2, shift2, N, HW, C, Creal, relu));
+  AST_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int ast_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,

@@ -180,6 +180,26 @@ int ast_norm_finalize(float* sums, int zero_sums, int64_t* num_batches_tracked /
 int ast_affine_act(const void* x, const float* scale, const float* shift, const void* r,
                    const float* scale2, const float* shift2, void* y, int N, int HW, int C,
                    int flags, int dtype, void* stream);
+/* Training-mode BatchNorm2d(+ReLU) [+ InstanceNorm2d of a second input: the ResBlock tail, style_encoder.py:76-83] in ONE
+ * launch, statistics finalize included: every workgroup reduces the statistics table tab1 ([rows1][C][2] = {sum x, sum x^2} over
+ * count1 pixels: the slot table of ast_igemm flags bit 3, or the [N][C][2] image sums of ast_chan_stats) into the per-channel
+ * scale / shift itself, then applies y = act(x*scale + shift [+ r*scale2[n] + shift2[n]]); tab2 = [N][C][2] sums of r.  Workgroup
+ * (0,0) writes out1 = [4][C] (mean, rstd, scale, shift) [out2 = [4][N*C]], updates the running statistics (momentum 0.1, unbiased
+ * variance) and num_batches_tracked.  The tables are only READ: the caller clears them (one memset per step for all of them).
+ * Replaces ast_norm_finalize + ast_affine_act (38 dependent single-wave launches per train step). */
+int ast_bn_apply_fwd(const void* x, const void* r, void* y, const float* tab1, int rows1, long count1, const float* tab2,
+                     const float* gamma1, const float* beta1, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     float eps1, const float* gamma2, const float* beta2, float eps2, float* out1, float* out2, int N, int HW, int C,
+                     int Creal, int flags /* bit0 ReLU */, int dtype, void* stream);
+/* Backward twin: tab3 = [rows][C][3] = {sum dz, sum dz*x, sum dz*r} (slot table of ast_igemm_bn over `count` pixels, or the
+ * [N][C][3] image sums of ast_norm_bwd_sums); dx = k1[c]*(dz, x, 1), dr = k2[n][c]*(dz, r, 1) with the coefficients formed in
+ * the kernel; dgamma / dbeta are ADDED by workgroup (0,0).  dz = dy * [fma(x, scale1, shift1) (+ fma(r, scale2[n], shift2[n])) > 0]
+ * when flags bit0 (ReLU).  dr != NULL needs rows == N.  Replaces ast_norm_bwd_finalize + ast_norm_bwd_apply. */
+int ast_bn_apply_bwd(const void* dy, const void* x, const void* r, void* dx, void* dr, const float* tab3, int rows, long count,
+                     const float* gamma1, const float* mean1, const float* rstd1, float* dgamma1, float* dbeta1,
+                     const float* gamma2, const float* mean2, const float* rstd2, float* dgamma2, float* dbeta2,
+                     const float* scale1, const float* shift1, const float* scale2, const float* shift2, int N, int HW, int C,
+                     int Creal, int flags, int dtype, void* stream);
 /* backward of the above followed by the norm backward:
  * dz = dy * (y>0 if relu); sums3[n][c] = {sum dz, sum dz*x, sum dz*r} */
 int ast_norm_bwd_sums(const void* dy, const void* y, const void* x, const void* r, float* sums3,

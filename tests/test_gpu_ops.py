@@ -69,6 +69,16 @@ def host_dropout_mask(seed, counter, n, p):
     return torch.from_numpy(out)
 
 
+@pytest.fixture(params=[True, False], ids=["fused-finalize", "separate-finalize"])
+def fused_finalize(request):
+    """Both forms of the normalisation passes: the statistics finalize inside the apply kernels (ast_bn_apply_fwd / _bwd, the
+    default) and the separate norm_finalize + affine_act launches it replaced (still the eval-mode and sync-BN path)."""
+    old = config.fused_finalize
+    config.fused_finalize = request.param
+    yield request.param
+    config.fused_finalize = old
+
+
 def sn_reference_weight(m, dim):
     """one power iteration + sigma, on a CPU copy of the buffers (oracle.spectral_weight)."""
     sd = {"weight_orig": m.weight_orig.detach().cpu().clone().requires_grad_(True),
@@ -357,7 +367,7 @@ def test_linear_fwd_bwd(rows, fin, fout, relu):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C,N,H,W", [(32, 3, 17, 21), (512, 4, 5, 10), (8, 2, 40, 33)])
-def test_batchnorm_relu(dtype, C, N, H, W):
+def test_batchnorm_relu(dtype, C, N, H, W, fused_finalize):
     torch.manual_seed(3)
     Cr = C if C != 8 else 2
     bn = nn.BatchNorm2d(Cr).to(DEV)
@@ -387,7 +397,45 @@ def test_batchnorm_relu(dtype, C, N, H, W):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_resblock_tail(dtype):
+@pytest.mark.parametrize("cin,cmid,cout,H,W,N", [(32, 64, 64, 20, 31, 3), (64, 256, 128, 9, 19, 2), (128, 512, 64, 5, 10, 4)])
+def test_conv_bn_relu_conv_chain(dtype, cin, cmid, cout, H, W, N, fused_finalize):
+    """conv -> BatchNorm2d -> ReLU -> conv with the batch statistics from the first GEMM's epilogue and the backward sums from the
+    second GEMM's data-gradient epilogue: slot tables of 64 / 16 / 8 rows (wide layers take fewer slots), reduced inside the apply
+    kernels (fused finalize) or by the separate finalize launches -- against plain PyTorch."""
+    torch.manual_seed(12)
+    c1 = spectral_norm(nn.Conv2d(cin, cmid, 3, padding=1)).to(DEV)
+    c2 = spectral_norm(nn.Conv2d(cmid, cout, 3, padding=1)).to(DEV)
+    bn = nn.BatchNorm2d(cmid).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    ref_bn = nn.BatchNorm2d(cmid)
+    ref_bn.load_state_dict({k: v.cpu() for k, v in bn.state_dict().items()})
+    w1, sd1 = sn_reference_weight(c1, 0)
+    w2, sd2 = sn_reference_weight(c2, 0)
+    x = torch.randn(N, cin, H, W)
+    xq = from_nhwc(to_nhwc(x, dtype), cin).clone().requires_grad_(True)
+    hr = torch.relu(ref_bn(F.conv2d(xq, w1, c1.bias.detach().cpu(), padding=1)))
+    yr = F.conv2d(hr, w2, c2.bias.detach().cpu(), padding=1)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    bank, (p1, p2) = make_bank([c1, c2], ["conv", "conv"], dtype)
+    bank.prepare(True)
+    assert ops.stat_slots(cmid) == {64: 64, 256: 16, 512: 8}[cmid]
+    xh = to_nhwc(x, dtype).requires_grad_(True)
+    h = AL.conv_bn_act(xh, p1, 3, 1, 1, bn, True, relu=True)
+    y = AL.conv(h, p2, 3, 1, 1, True)
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    assert rel_err(from_nhwc(y, cout), yr) < tol
+    y.backward(to_nhwc(gy, dtype))
+    assert rel_err(from_nhwc(xh.grad, cin), xq.grad) < 3 * tol
+    assert rel_err(bn.weight.grad, ref_bn.weight.grad) < 3 * tol and rel_err(bn.bias.grad, ref_bn.bias.grad) < 3 * tol
+    assert rel_err(c1.weight_orig.grad, sd1["weight_orig"].grad) < 3 * tol and rel_err(c2.weight_orig.grad, sd2["weight_orig"].grad) < 3 * tol
+    assert rel_err(bn.running_mean, ref_bn.running_mean) < 1e-3 and rel_err(bn.running_var, ref_bn.running_var) < 1e-3
+    assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_resblock_tail(dtype, fused_finalize):
     torch.manual_seed(4)
     N, C, H, W = 3, 64, 9, 13
     bn, inn = nn.BatchNorm2d(C).to(DEV), nn.InstanceNorm2d(C, affine=True).to(DEV)
