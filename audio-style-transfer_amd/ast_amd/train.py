@@ -100,28 +100,24 @@ class FlatGroup:
         """Mean of the flat gradient over ranks: ONE collective per group.  wire_dtype=bf16 halves the bytes on the
         xGMI ring (124 MB -> 62 MB for encoders+decoder; the all-reduce sits on the critical path between backward and
         Adam): cast kernel -> all-reduce -> cast back + scale.  Used in the bf16 compute mode only."""
-        from .parallel import allreduce_mean_
 
         def scale(t, s):
             check(lib().ast_scale(ptr(t), None, s, ptr(t), t.numel(), 0, stream()), "ast_scale")
-        if force and world <= 1:                       # one-rank rehearsal of the collective path (tests): the same calls
-            if wire_dtype == torch.bfloat16 and self.n >= (1 << 20):
-                if getattr(self, "_wire", None) is None:
-                    self._wire = torch.empty(self.n, dtype=torch.bfloat16, device=self.flat_g.device)
-                self._wire.zero_()
-                dist.all_reduce(self._wire, op=dist.ReduceOp.SUM)      # (the gradient itself stays f32-exact: the wire is a dummy here)
-            else:
-                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+        if world <= 1 and not force:
             return
-        if world > 1 and wire_dtype == torch.bfloat16 and self.n >= (1 << 20):
+        # force (tests): a one-rank group runs the SAME calls as world > 1 -- cast, collective, cast back, scale
+        if wire_dtype == torch.bfloat16 and self.n >= (1 << 20):
             if getattr(self, "_wire", None) is None:
                 self._wire = torch.empty(self.n, dtype=torch.bfloat16, device=self.flat_g.device)
             check(lib().ast_cast(ptr(self.flat_g), 0, ptr(self._wire), 1, self.n, stream()), "ast_cast")
             dist.all_reduce(self._wire, op=dist.ReduceOp.SUM)
             check(lib().ast_cast(ptr(self._wire), 1, ptr(self.flat_g), 0, self.n, stream()), "ast_cast")
-            scale(self.flat_g, 1.0 / world)
+            if world > 1:
+                scale(self.flat_g, 1.0 / world)
             return
-        allreduce_mean_(self.flat_g, world, scale)
+        dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+        if world > 1:
+            scale(self.flat_g, 1.0 / world)
 
     def adam(self, hyper, betas, eps, clip=True):
         """hyper: DEVICE tensor [lr, max_norm], read by the kernel at run time (a replayed graph follows an LR schedule).

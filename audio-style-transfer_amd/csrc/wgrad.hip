@@ -80,7 +80,10 @@ __device__ __forceinline__ void flush_tile_rows(const f32x4 (&acc)[RT][CTW], flo
   }
 }
 
-inline bool wg_flush_direct() { const char* e = getenv("AST_WGRAD_FLUSH_LDS"); return e && atoi(e) == 0; }
+// Default: atomics straight from the accumulator registers.  The through-LDS form (AST_WGRAD_FLUSH_LDS=1: 256 contiguous bytes per
+// atomic wave-instruction) measured 1-1.5 us SLOWER per layer with 8 gradient replicas (64-channel layer 40.1 -> 41.5 us, 128: 41.0 ->
+// 42.2, 256: 41.8 -> 43.3; profiles/r03/wg_flush.txt): at ~11 adders per address the 4 x 64 B shape is not what bounds the flush.
+inline bool wg_flush_direct() { const char* e = getenv("AST_WGRAD_FLUSH_LDS"); return !(e && atoi(e) != 0); }
 static thread_local int g_wg_nrep = 1;
 static thread_local long g_wg_rep_stride = 0;
 template <typename T> struct WgradCfg;

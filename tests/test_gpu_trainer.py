@@ -344,8 +344,10 @@ def test_collectives_inside_the_captured_step_one_rank():
         assert tr._dist_in_graph is True, "the probe refused all-reduce capture on this stack"
         (graphs, _, _), = tr._graphs.values()
         assert len(graphs) == 1
+        # bf16 at B = 2: the margin term moves by ~1e-2 with the summation order of the statistics atomics alone (two plain
+        # trainers differ by that much), and the collective path rounds the gradient to the bf16 wire
         for a, b in zip(losses, ref_losses):
-            assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (losses, ref_losses)
+            assert abs(a - b) <= 1e-2 * max(1.0, abs(b)), (losses, ref_losses)
     finally:
         os.environ.pop("AST_FORCE_COLLECTIVES", None)
         dist.destroy_process_group()
