@@ -43,4 +43,7 @@ wgrad_replicas = int(_os.environ.get("AST_WGRAD_REPLICAS", "8"))
 # BatchNorm / InstanceNorm statistics finalize folded into the apply passes (ast_bn_apply_fwd / _bwd): every workgroup of the
 # apply pass reduces the statistics table itself, so the ~78 single-wave finalize launches of a step disappear from its
 # dependency chain (AST_FUSED_FINALIZE=0 keeps norm_finalize + affine_act: the reference path for tests and A/B timing).
-fused_finalize = _os.environ.get("AST_FUSED_FINALIZE", "1") != "0"
+# Opt-in: measured on one box against the separate launches, three runs each: 6.35 / 6.29 / 6.37 ms per step fused against
+# 6.23 / 6.28 / 6.35 separate (profiles/r03/bisect6.txt) -- the table reduction in front of every apply workgroup costs what the
+# finalize launch cost, the 78 nodes it removes are worth ~0.1 ms of dispatch, and the sum is a wash.
+fused_finalize = _os.environ.get("AST_FUSED_FINALIZE", "0") != "0"

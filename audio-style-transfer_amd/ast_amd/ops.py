@@ -155,11 +155,13 @@ def stat_table(n, device):
 
 def stat_arena_reset(device):
     """Clear every table handed out so far (one memset on the current stream) and start over.  Call where every stream that
-    used a table has been joined into the current one: the start of a train step."""
+    used a table has been joined into the current one: the start of a train step.  With the separate finalize launches
+    (config.fused_finalize off) every table comes back clean from its finalize kernel, and only the allocation rewinds."""
     a = _StatArena.by_device.get(torch.device(device))
     if a is None or a[2] == 0:
         return
-    a[0][:a[2]].zero_()
+    if config.fused_finalize or _SyncBN.world > 1:
+        a[0][:a[2]].zero_()
     a[1] = 0
 
 

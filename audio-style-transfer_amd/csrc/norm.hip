@@ -488,7 +488,10 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__
   const size_t stride = (size_t)gridDim.x * 256;
   const bool hoist = (256 % U) == 0;
   const bool remask = relu != 0;                   // mask recomputed from the pre-activation fma(x, sc1, sf1) [+ fma(r, sc2[n], sf2[n])]
-  float a1[8], b1[8], a2[8], b2[8], ka[8][3], kb[8][3];
+  // the 8 x 3 coefficients of the thread's channel unit as six 16-byte LDS reads per branch, indexed by compile-time constants only
+  // (as [8][3] arrays filled element by element they went to scratch memory: 208 B per lane, and the pixel loop ran 3x slower)
+  float a1[8], b1[8], a2[8], b2[8];
+  f32x4 kaq[6], kbq[6];
   auto load_coef = [&](int u) __attribute__((always_inline)) {
     if (remask) {
       U8<float>::load(sc1 + u * 8, a1);
@@ -498,11 +501,13 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__
         U8<float>::load(sf2 + (size_t)n * C + u * 8, b2);
       }
     }
+    const f32x4* ka4 = reinterpret_cast<const f32x4*>(kc + u * 24);
+    const f32x4* kb4 = reinterpret_cast<const f32x4*>(kc + 3 * C + u * 24);
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) { ka[k][q] = kc[(u * 8 + k) * 3 + q]; if (dr) kb[k][q] = kc[3 * C + (u * 8 + k) * 3 + q]; }
+    for (int q = 0; q < 6; ++q) { kaq[q] = ka4[q]; kbq[q] = dr ? kb4[q] : f32x4{0.f, 0.f, 0.f, 0.f}; }
   };
+#define KA(k, q) kaq[((k) * 3 + (q)) >> 2][((k) * 3 + (q)) & 3]
+#define KB(k, q) kbq[((k) * 3 + (q)) >> 2][((k) * 3 + (q)) & 3]
   const size_t j0 = (size_t)blockIdx.x * 256 + tid;
   if (hoist) load_coef((int)(j0 % U));
   for (size_t j = j0; j < per_img; j += stride) {
@@ -524,14 +529,16 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const T* __restrict__
       for (int k = 0; k < 8; ++k) dz[k] = pre[k] > 0.f ? dz[k] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = ka[k][0] * dz[k] + ka[k][1] * v[k] + ka[k][2];
+    for (int k = 0; k < 8; ++k) o[k] = KA(k, 0) * dz[k] + KA(k, 1) * v[k] + KA(k, 2);
     U8<T>::store(dx + i * 8, o);
     if (dr) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = kb[k][0] * dz[k] + kb[k][1] * vr[k] + kb[k][2];
+      for (int k = 0; k < 8; ++k) o[k] = KB(k, 0) * dz[k] + KB(k, 1) * vr[k] + KB(k, 2);
       U8<T>::store(dr + i * 8, o);
     }
   }
+#undef KA
+#undef KB
 }
 
 // ---- LayerNorm over the last dim (rows x D), one wave per row, f32 --------------

@@ -1,0 +1,13 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r3; mkdir -p $O
+ms() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])"; }
+{
+for i in 1 2; do
+  echo -n "r2 pkg + r2 bench : "; (cd _ab_r2 && timeout -k 10 120 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | ms)
+  echo -n "r2 pkg + c1 bench : "; (cd _ab_r2 && timeout -k 10 120 python bench_c1.py --no-extras --no-cpu-baseline --no-roofline 2>/dev/null | ms)
+  echo -n "c1 pkg + r2 bench : "; (cd _ab_c1 && timeout -k 10 120 python bench_r2.py --no-cpu-baseline --no-roofline 2>/dev/null | ms)
+  echo -n "c1 pkg + c1 bench : "; (cd _ab_c1 && timeout -k 10 120 python bench.py --no-extras --no-cpu-baseline --no-roofline 2>/dev/null | ms)
+done
+} | tee $O/bisect5.txt
