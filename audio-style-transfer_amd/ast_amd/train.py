@@ -250,12 +250,6 @@ class Trainer:
                             y_emb = self.decoder.encode_target(y)
             for st in self._streams:
                 main.wait_stream(st)
-            if os.environ.get("AST_COLLAPSE_JOINS") == "1":
-                # experiment: one trivial kernel after the three-way join, so that everything downstream (and the side stream forked
-                # next) hangs on ONE graph node instead of the last node of every branch
-                if getattr(self, "_join_ctr", None) is None:
-                    self._join_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
-                check(lib().ast_counter_incr(ptr(self._join_ctr), stream()), "ast_counter_incr")
             for t in (style_emb, class_emb, content_emb, y_emb):
                 if t is not None:
                     t.record_stream(main)

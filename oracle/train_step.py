@@ -57,10 +57,14 @@ class OracleTrainer:
         self.embeddings = (style.detach(), cls.detach(), content.detach())
         return terms, out
 
-    def step(self, x, labels, apply_g=True):
+    def step(self, x, labels, apply_g=True, use=TERMS):
+        """`use`: the generator-phase terms that enter the total (TrainConfig's use_hsic / use_nce / use_adv gates)."""
         terms, _ = self.forward_losses(x, labels)
         self.og.zero_grad()
-        total = terms["rec"] + terms["nce"] + terms["margin"] + terms["hsic"] + terms["adv_g"]
+        total = None
+        for k in ("rec", "nce", "margin", "hsic", "adv_g"):          # (fixed order: the total's last bits are part of the fixtures)
+            if k in use:
+                total = terms[k] if total is None else total + terms[k]
         total.backward()
         # the raw (unclipped) generator gradient by model and parameter name, for gradient parity checks
         self.raw_grads = {t: {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in self.sds[t].items() if v.requires_grad}

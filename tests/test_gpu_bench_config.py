@@ -20,22 +20,23 @@ B, S = 8, 2
 _ORACLE = {}
 
 
-def oracle_reference():
-    """One oracle step at B=8,S=2 (a few seconds of CPU), shared by the two dtype cases."""
-    if not _ORACLE:
+def oracle_reference(use_hsic=True):
+    """One oracle step at B=8,S=2 (a few seconds of CPU), shared by the dtype cases."""
+    if use_hsic not in _ORACLE:
         ot = OracleTrainer()
         x, labels = sp.seeded_input(B, S), sp.balanced_labels(B)
-        _ORACLE["losses"] = ot.step(x, labels, apply_g=False)
-        _ORACLE["rec_parts"] = {k: float(v) for k, v in ot.rec_parts.items()}
-        _ORACLE["grads"] = ot.raw_grads
-        _ORACLE["gnorm"] = ot.gnorm
-        _ORACLE["disc_after"] = {k: v.detach().clone() for k, v in ot.sds["disc"].items() if v.requires_grad}
-    return _ORACLE
+        r = _ORACLE[use_hsic] = {}
+        r["losses"] = ot.step(x, labels, apply_g=False, use=OracleTrainer.TERMS if use_hsic else ("rec", "nce", "margin", "adv_g"))
+        r["rec_parts"] = {k: float(v) for k, v in ot.rec_parts.items()}
+        r["grads"] = ot.raw_grads
+        r["gnorm"] = ot.gnorm
+        r["disc_after"] = {k: v.detach().clone() for k, v in ot.sds["disc"].items() if v.requires_grad}
+    return _ORACLE[use_hsic]
 
 
-def seeded_trainer(dtype, use_graph=True):
+def seeded_trainer(dtype, use_graph=True, use_hsic=True):
     ast_amd.set_compute_dtype(dtype)
-    tr = train.Trainer(train.TrainConfig(use_graph=use_graph, dropout=False, keep_grads=True), seed=7)
+    tr = train.Trainer(train.TrainConfig(use_graph=use_graph, dropout=False, keep_grads=True, use_hsic=use_hsic), seed=7)
     for tag, m in (("style", tr.style), ("content", tr.content), ("decoder", tr.decoder), ("disc", tr.disc)):
         # in place: the parameters are views of the trainer's flat buffers
         m.load_state_dict({k: v.to("cuda") for k, v in sp.seeded_state_dict(m.state_dict(), tag=tag).items()})
@@ -75,18 +76,25 @@ CASES = {
     # Measured at this configuration (GPUTEST log line "[bench-config parity] bf16"): rec 1.4e-4, nce 6e-5, adv_g 2e-4,
     # adv_d 3.8e-4, total 1.9e-3 (it contains the margin term), hsic 3.2e-2 (a 7e-3-sized statistic of embedding
     # differences); gradients style 0.25, content 0.053, decoder 0.055.
-    # Three runs on different boxes gave hsic 2.9 / 3.2 / 3.4e-2 and total 1.4e-4 .. 1.9e-3 (f32 atomic order differs from
-    # run to run and bf16 rounding amplifies it), one run exceeded a 2x bound: the bounds are 3x the largest value seen.
-    "bf16": (torch.bfloat16, {"*": 2e-3, "total": 6e-3, "hsic": 0.1}, {"style": 0.6, "content": 0.16, "decoder": 0.16}),
+    # Round 3 (profiles/r03/bf16_stage_ablation_*.txt): NO stage is responsible -- rounding only the INPUT image to bf16 already
+    # gives 0.13 on the margin gradient, every block adds 0.05-0.17, the weights 0.17: the margin / HSIC gradients are differences of
+    # nearly equal per-image contributions (||c0 - c1|| = 1.3 against ||c|| = 16 with these seeded parameters), so f32 storage of
+    # a few tensors cannot repair them.  Bounds = 2x the values measured over five runs of round 3: style 0.241-0.247, decoder
+    # 0.043-0.044; content is BIMODAL, 0.053 (three runs) or 0.164 (one run): HSIC's kernel width is the median of the pairwise
+    # embedding distances (losses.py:170-171), and bf16 noise can move the median to the neighbouring pair -- the HSIC value then
+    # moves from 1.9-2.4 % to 3.4 % off and its gradient with it.  The second case below takes HSIC out and bounds content tightly.
+    "bf16": (torch.bfloat16, {"*": 2e-3, "total": 6e-3, "hsic": 0.07}, {"style": 0.5, "content": 0.33, "decoder": 0.09}),
+    "bf16-nohsic": (torch.bfloat16, {"*": 2e-3, "total": 6e-3}, {"style": 0.5, "content": 0.2, "decoder": 0.09}),
 }
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "bf16-nohsic"])
 def test_benchmarked_configuration_vs_oracle(mode):
     dtype, tol, gtol = CASES[mode]
-    ref = oracle_reference()
+    use_hsic = mode != "bf16-nohsic"
+    ref = oracle_reference(use_hsic)
     try:
-        tr = seeded_trainer(dtype)
+        tr = seeded_trainer(dtype, use_hsic=use_hsic)
         x, labels = sp.seeded_input(B, S).cuda(), sp.balanced_labels(B)
         out = {k: float(v) for k, v in tr.step(x, labels).items()}       # capture + first replay: step 1
         torch.cuda.synchronize()
@@ -94,6 +102,8 @@ def test_benchmarked_configuration_vs_oracle(mode):
         print(f"[bench-config parity] {mode}: loss rel err " + ", ".join(
             f"{k} {abs(out[k] - ref['losses'][k]) / abs(ref['losses'][k]):.1e}" for k in out))
         for k in ("rec", "nce", "hsic", "adv_d", "adv_g", "total"):
+            if k not in out:
+                continue
             t = tol.get(k, tol["*"])
             assert math.isclose(out[k], ref["losses"][k], rel_tol=t, abs_tol=1e-5), (mode, k, out[k], ref["losses"][k])
         # the discriminator after ITS optimiser step.  The first Adam update is +-lr per parameter (sign of the gradient):
