@@ -15,7 +15,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import config, ops
+from . import config, ops, streams
 from ._lib import LinWg, WeightDesc, check, dcode, lib, ptr, stream
 from .ops import PackedWeight, pad8
 
@@ -188,7 +188,7 @@ class WeightBank:
                 if self._flush_stream is None:
                     self._flush_stream = torch.cuda.Stream(device=self.d_tiles.device)
                 side = self._flush_stream
-                side.wait_stream(torch.cuda.current_stream())
+                streams.fork(side, torch.cuda.current_stream())
                 _ParallelFlush.pending.append(side)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 check(lib().ast_weight_grads_flush_t(ptr(self.d_train), ptr(self.d_tiles), self.ntiles, stream()),
@@ -242,7 +242,7 @@ def parallel_flush():
         _ParallelFlush.active = False
         cur = torch.cuda.current_stream()
         for s in _ParallelFlush.pending:
-            cur.wait_stream(s)
+            streams.join(cur, s)
         _ParallelFlush.pending = []
 
 

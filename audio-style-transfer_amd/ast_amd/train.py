@@ -19,7 +19,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import config, ops
+from . import config, ops, streams
 from ._lib import check, lib, ptr, stream
 from .content_encoder import ContentEncoder
 from .discriminator import Discriminator
@@ -233,7 +233,7 @@ class Trainer:
                 self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
             s1, s2, s3 = self._streams
             for st in self._streams:                 # fork after the shared input conversion (shared_nhwc, on main)
-                st.wait_stream(main)
+                streams.fork(st, main)
                 if ops._SharedInput.y is not None:
                     ops._SharedInput.y.record_stream(st)
             order = os.environ.get("AST_BRANCH_ORDER", "ysc")   # creation order = reverse backward priority; y first measured 0.03 ms better
@@ -249,7 +249,7 @@ class Trainer:
                         if not self._simple:
                             y_emb = self.decoder.encode_target(y)
             for st in self._streams:
-                main.wait_stream(st)
+                streams.join(main, st)
             for t in (style_emb, class_emb, content_emb, y_emb):
                 if t is not None:
                     t.record_stream(main)
@@ -361,11 +361,11 @@ class Trainer:
             if self._stream_d is None:
                 self._stream_d = torch.cuda.Stream(device=self.device)
             sd = self._stream_d
-            sd.wait_stream(main)
+            streams.fork(sd, main)
             with torch.cuda.stream(sd):
                 self.D.adam(self.hyper[H_LR_D:H_LR_D + 2], c.betas, c.eps, c.max_grad_norm > 0)
                 self.D.zero_grad()
-            self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb, before_adv=lambda: main.wait_stream(sd), side=sd)
+            self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb, before_adv=lambda: streams.join(main, sd), side=sd)
         else:
             self.D.adam(self.hyper[H_LR_D:H_LR_D + 2], c.betas, c.eps, c.max_grad_norm > 0)
             self.D.zero_grad()
@@ -399,7 +399,7 @@ class Trainer:
         if self._stream_d is None:
             self._stream_d = torch.cuda.Stream(device=self.device)
         sd = self._stream_d
-        sd.wait_stream(main)
+        streams.fork(sd, main)
         with torch.cuda.stream(sd):
             d_loss = self._d_phase(style_emb, class_emb, content_emb, labels_host)
             if self._dist:
@@ -409,7 +409,7 @@ class Trainer:
         d_loss.record_stream(main)
         # margin / InfoNCE / HSIC go to the side stream too, but are CREATED after the decoder's nodes (inside _g_phase):
         # created before them, their backward ran after the decoder's and held the three encoder branches back (+0.9 ms)
-        self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb, before_adv=lambda: main.wait_stream(sd), side=sd)
+        self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb, before_adv=lambda: streams.join(main, sd), side=sd)
         self._parts["adv_d"] = d_loss.detach()
         if self._dist:
             self.G.all_reduce(self.world, self._wire_dtype, force=self._force_coll)
@@ -429,7 +429,7 @@ class Trainer:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         held = []
         st0 = self._streams[0]
-        st0.wait_stream(main)
+        streams.fork(st0, main)
         with torch.cuda.stream(st0):                 # gradients are first touched in the backward pass, after the branches join
             self.G.zero_grad()
             self.D.zero_grad()
@@ -438,7 +438,7 @@ class Trainer:
             bank = _module_bank(mod)
             if bank.hold:
                 continue
-            st.wait_stream(main)
+            streams.fork(st, main)
             with torch.cuda.stream(st):
                 bank.prepare(True)
             bank.hold = True
@@ -538,14 +538,14 @@ class Trainer:
                 if self._stream_fe is None:
                     self._stream_fe = torch.cuda.Stream(device=self.device)
                 main, side = torch.cuda.current_stream(), self._stream_fe
-                side.wait_stream(main)
+                streams.fork(side, main)
                 with torch.cuda.stream(side):
                     cqt_sections(waves, x, *self._frontend_cqt)
             else:
                 cqt_sections(waves, x, *self._frontend_cqt)
         stft_sections(waves, mean, std, n_sections=x.shape[1], F_total=x.shape[-1], out=x)
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+            streams.join(torch.cuda.current_stream(), side)
 
     def step(self, x: torch.Tensor, labels_host: torch.Tensor):
         """x: (B,S,2,287,597) f32 on the device; labels on the HOST (balanced [0]*B/2+[1]*B/2 as
@@ -689,7 +689,7 @@ class Trainer:
         if not segmented:
             dot = os.environ.get("AST_GRAPH_DOT")    # tools/graph_critical_path.py: the captured step's nodes and edges
             gph = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gph, **({"capture_error_mode": "thread_local"} if self._dist else {})):
+            with torch.cuda.graph(gph, **({"capture_error_mode": "thread_local"} if self._dist else {})), streams.capture_origin():
                 outs = self._step_body(static_x, labels_host)
             if dot:
                 import ctypes
@@ -705,11 +705,11 @@ class Trainer:
             # while capturing segment B, so B must see A's activations at the same addresses
             graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
             pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(graphs[0], pool=pool):
+            with torch.cuda.graph(graphs[0], pool=pool), streams.capture_origin():
                 self._seg_a(static_x, labels_host)
-            with torch.cuda.graph(graphs[1], pool=pool):
+            with torch.cuda.graph(graphs[1], pool=pool), streams.capture_origin():
                 self._seg_b(static_x, labels_host)
-            with torch.cuda.graph(graphs[2], pool=pool):
+            with torch.cuda.graph(graphs[2], pool=pool), streams.capture_origin():
                 self._seg_c(static_x, labels_host)
             outs = self._parts
         with torch.no_grad():

@@ -19,6 +19,7 @@ Patterns
   nested_direct second-level stream joined straight into the origin stream
   nested_keep   nested with every Event object kept alive until the capture has ended
   nested_via_main  the second-level stream is joined into the ORIGIN stream and the first-level stream then waits for the origin
+  nested_helper    the nested pattern written with ast_amd.streams.fork / join (the guard routes the child's join through the origin)
   sibling       two first-level streams; one waits for an event of the other, both join the origin
   tail       the side stream gets MORE work after its join event was recorded (an unjoined tail: what an autograd node that
              returns no gradient leaves behind when its backward runs on a side stream)
@@ -34,7 +35,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "audio-style-transfer_amd"))
 
-PATTERNS = ("seq", "fan", "keep", "nested", "nested_pre", "nested_fresh", "nested_direct", "nested_keep", "nested_via_main", "sibling", "tail", "unjoined", "bwd", "bwd_leaf")
+PATTERNS = ("seq", "fan", "keep", "nested", "nested_pre", "nested_fresh", "nested_direct", "nested_keep", "nested_via_main", "nested_helper", "sibling", "tail", "unjoined", "bwd", "bwd_leaf")
 
 
 def run_pattern(pattern, n):
@@ -152,6 +153,19 @@ def run_pattern(pattern, n):
                 a.wait_stream(main)                # ... and let the first-level stream wait for the origin
                 scale(bufs[n], bufs[n + 1], 1.0, a)
                 main.wait_stream(a)
+            expect = [(i, i + 1.0) for i in range(n)] + [(n + 1, float(n))]
+        elif pattern == "nested_helper":
+            from ast_amd import streams as ST
+            a, b = sides[0], sides[1]
+            with ST.capture_origin(main):
+                for i in range(n):
+                    ST.fork(a, main)
+                    scale(x, bufs[i], i + 1, a)
+                    ST.fork(b, a)
+                    scale(bufs[i], bufs[n], 1.0, b)
+                    ST.join(a, b)                  # would be the crashing a.wait_stream(b): goes through the origin stream
+                    scale(bufs[n], bufs[n + 1], 1.0, a)
+                    ST.join(main, a)
             expect = [(i, i + 1.0) for i in range(n)] + [(n + 1, float(n))]
         elif pattern == "sibling":
             a, b = sides[0], sides[1]
