@@ -160,7 +160,7 @@ def stat_arena_reset(device):
     a = _StatArena.by_device.get(torch.device(device))
     if a is None or a[2] == 0:
         return
-    if config.fused_finalize or _SyncBN.world > 1:
+    if config.fused_finalize or _SyncBN.active:
         a[0][:a[2]].zero_()
     a[1] = 0
 
@@ -314,7 +314,7 @@ class Conv2dFn(torch.autograd.Function):
 def _bn_link_ready(link, geoms, x):
     """The BNLink of a conv input, armed with a zeroed [64][C][3] slot table, when every data-gradient launch can take the
     fused sums (no split-K plan); else None and the BatchNorm backward runs its own pass."""
-    if link is None or link.x is None or not config.fused_bn_bwd or _SyncBN.world > 1:
+    if link is None or link.x is None or not config.fused_bn_bwd or _SyncBN.active:
         return None
     if not all(stats_fusable(g, dcode(x.dtype)) for g in geoms):
         return None
@@ -610,14 +610,18 @@ def _stats(x):
 class _SyncBN:
     """Cross-rank BatchNorm statistics: with world > 1 the per-image sums of every BatchNorm2d are
     all-reduced before the finalize, forward and backward, so the normalisation is over all B*S images of the global
-    batch as in the single-process reference.  Eager mode only (a collective per BN layer cannot sit inside the
-    captured step); the default data-parallel mode keeps per-rank statistics."""
+    batch as in the single-process reference.  The exchange is a clone + all-reduce + finalize on the current stream: with the
+    NCCL (RCCL) backend it is captured into the step's hipGraph like the gradient all-reduce (Trainer, loss-matched mode: one
+    stream, so that every collective forks from and joins into the capture's ORIGIN stream -- ast_amd/streams.py); with gloo it
+    runs eagerly.  The default data-parallel mode keeps per-rank statistics."""
     world = 1
     group = None
+    active = False      # world > 1, or a one-rank group whose collectives are forced on (the single-GPU rehearsal of this path)
 
 
-def set_sync_bn(world=1, group=None):
+def set_sync_bn(world=1, group=None, force=False):
     _SyncBN.world, _SyncBN.group = int(world), group
+    _SyncBN.active = _SyncBN.world > 1 or bool(force)
 
 
 def _global_sums(sums, n_floats):
@@ -635,7 +639,7 @@ def _bn_batch_stats(x, gamma, beta, bn, stats=None):
     rows = stats.numel() // (2 * C) if stats is not None else N
     sums = stats if stats is not None else _stats(x)
     pixels = N * H * W
-    if _SyncBN.world > 1:
+    if _SyncBN.active:
         g = _global_sums(sums, rows * C * 2)
         sums[:rows * C * 2].zero_()
         out = torch.empty((4, C), dtype=torch.float32, device=x.device)
@@ -665,7 +669,7 @@ class BatchNormActFn(torch.autograd.Function):
         N, H, W, C = x.shape
         Creal = gamma.numel()
         ctx.link = None
-        ctx.fused = bool(training and config.fused_finalize and _SyncBN.world == 1)
+        ctx.fused = bool(training and config.fused_finalize and not _SyncBN.active)
         if ctx.fused:
             # statistics finalize + apply in ONE launch (ast_bn_apply_fwd): the table is reduced by every workgroup
             tab = stats if stats is not None else _stats(x)
@@ -733,7 +737,7 @@ class BatchNormActFn(torch.autograd.Function):
             check(lib().ast_norm_bwd_sums_pre(ptr(dy), ptr(y), ptr(x), None, ptr(sums3), N, H * W, C, int(ctx.relu),
                                               dcode(x.dtype), 1, ptr(scale) if pre else None, ptr(shift) if pre else None, None, None,
                                               stream()), "ast_norm_bwd_sums")
-            gsum = _global_sums(sums3, N * C * 3) if _SyncBN.world > 1 else None
+            gsum = _global_sums(sums3, N * C * 3) if _SyncBN.active else None
             # gamma/beta gradients come from the LOCAL sums (the gradient all-reduce averages them over ranks)
             check(lib().ast_norm_bwd_finalize(ptr(sums3), 1, N, H * W, C, gamma.numel(), ptr(gamma), ptr(mean), ptr(rstd),
                                               ptr(acc_grad(gamma)), ptr(acc_grad(beta)), ptr(k1),
@@ -756,7 +760,7 @@ class ResTailFn(torch.autograd.Function):
     def forward(ctx, c2, ds, g1, b1, g2, b2, bn, inn, training, stats=None, in_stats=None):
         N, H, W, C = c2.shape
         Creal = g1.numel()
-        ctx.fused = bool(training and config.fused_finalize and _SyncBN.world == 1)
+        ctx.fused = bool(training and config.fused_finalize and not _SyncBN.active)
         if ctx.fused:
             tab1 = stats if stats is not None else _stats(c2)
             tab2 = in_stats if in_stats is not None else _stats(ds)
@@ -810,7 +814,7 @@ class ResTailFn(torch.autograd.Function):
                                           1, *coef, stream()), "ast_norm_bwd_sums")
         k1 = torch.empty((C, 3), dtype=torch.float32, device=dev)
         k2 = torch.empty((N, C, 3), dtype=torch.float32, device=dev)
-        gsum = _global_sums(sums3, N * C * 3) if _SyncBN.world > 1 else None
+        gsum = _global_sums(sums3, N * C * 3) if _SyncBN.active else None
         check(lib().ast_norm_bwd_finalize(ptr(sums3), 1, N, H * W, C, g1.numel(), ptr(g1), ptr(m1), ptr(r1),
                                           ptr(acc_grad(g1)), ptr(acc_grad(b1)), ptr(k1), ptr(g2), ptr(m2), ptr(r2),
                                           ptr(acc_grad(g2)), ptr(acc_grad(b2)), ptr(k2), stream()),

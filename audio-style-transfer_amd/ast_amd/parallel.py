@@ -50,13 +50,14 @@ class GatherRowsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, rank, world, group):
-        order = global_row_order(x.shape[0] * world, world)
-        ctx.rank, ctx.world, ctx.group, ctx.order = rank, world, group, order
-        mine = [k for k, (r, _) in enumerate(order) if r == rank]
+        ctx.group = group
+        ctx.idx = idx = _my_rows(x.shape[0] * world, rank, world, x.device)
         # a SUM all-reduce of rows scattered into a zero global buffer: a few KB, and (unlike all_gather on
-        # device tensors) available on both backends the tests use (nccl = RCCL, gloo)
-        out = torch.zeros((len(order),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        out[mine] = x.detach()
+        # device tensors) available on both backends the tests use (nccl = RCCL, gloo).  The row indices are a cached DEVICE
+        # tensor (built once, outside any capture): index_copy_ / index_select launch plain kernels, so the gather is
+        # capturable into the step's hipGraph (a Python list index would upload its indices on every call).
+        out = torch.zeros((x.shape[0] * world,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        out.index_copy_(0, idx, x.detach())
         dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
         return out
 
@@ -64,12 +65,25 @@ class GatherRowsFn(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous().clone()
         dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-        mine = [k for k, (r, _) in enumerate(ctx.order) if r == ctx.rank]        # ascending local row
-        return g[mine], None, None, None
+        return g.index_select(0, ctx.idx), None, None, None          # this rank's rows, ascending local row
 
 
-def gather_rows(x: torch.Tensor, rank: int, world: int, group=None) -> torch.Tensor:
-    return x if world == 1 else GatherRowsFn.apply(x, rank, world, group)
+_row_idx = {}
+
+
+def _my_rows(global_batch, rank, world, device):
+    """Global rows owned by `rank` (ascending local row) as a cached device index tensor."""
+    key = (global_batch, rank, world, str(device))
+    t = _row_idx.get(key)
+    if t is None:
+        order = global_row_order(global_batch, world)
+        t = _row_idx[key] = torch.tensor([k for k, (r, _) in enumerate(order) if r == rank], dtype=torch.long, device=device)
+    return t
+
+
+def gather_rows(x: torch.Tensor, rank: int, world: int, group=None, force=False) -> torch.Tensor:
+    """force: run the collective path on a one-rank group too (the single-GPU rehearsal of the loss-matched mode)."""
+    return x if (world == 1 and not force) else GatherRowsFn.apply(x, rank, world, group)
 
 
 def global_labels(local_labels: torch.Tensor, world: int) -> torch.Tensor:

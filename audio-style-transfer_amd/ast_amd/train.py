@@ -56,9 +56,11 @@ class TrainConfig:
     dropout: bool = True          # nn.Dropout(0.1) as constructed by the reference
     # world > 1 only: reproduce the single-process step on the GLOBAL batch (SURVEY 8(e)(2)+(3)): BatchNorm statistics
     # all-reduced per layer, style/content embeddings all-gathered for InfoNCE / HSIC / class prototypes / margin.
-    # Needs a collective per BN layer, so the step runs eagerly; the default keeps per-rank statistics and losses
-    # (valid DDP, not loss-matched) and runs as three hipGraphs.
+    # Runs on ONE stream (every collective then forks from and joins into the capture's origin stream: streams.py) and, over
+    # RCCL, as ONE captured hipGraph with all ~70 small collectives inside; over gloo eagerly.  The gradient exchange is
+    # bucketed by model (decoder, content encoder, style encoder) and overlapped with the rest of the backward pass.
     loss_matched: bool = False
+    bucketed: bool = True         # loss-matched mode: per-model gradient buckets, all-reduced while the backward pass goes on
     decoder: str = "new"          # "new" = new_decoder.Decoder (north star); "simple" = SimpleDecoder_TransformerOnly.Decoder (8(f)1)
     grad_wire: str = "auto"       # dtype of the gradient all-reduce: "f32", "bf16", or "auto" = bf16 in the bf16 compute
                                   # mode over RCCL, else f32 (env AST_GRAD_WIRE overrides)
@@ -92,6 +94,13 @@ class FlatGroup:
             p.data = self.flat_p[off:off + k].view(p.shape)
             p.grad = self.flat_g[off:off + k].view(p.shape)
             off += (k + 3) // 4 * 4
+        # [offset, length) of every module's parameters inside the flat buffers (the modules' parameters are contiguous)
+        self.slices, off = [], 0
+        for m in modules:
+            k = sum((p.numel() + 3) // 4 * 4 for p in m.parameters())
+            self.slices.append((off, k))
+            off += k
+        self._pending = []
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -118,6 +127,31 @@ class FlatGroup:
         dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
         if world > 1:
             scale(self.flat_g, 1.0 / world)
+
+    def all_reduce_bucket(self, index, world, wire_dtype=torch.float32, force=False):
+        """Start the SUM all-reduce of module `index`'s slice of the flat gradient (async: the collective runs on the process
+        group's stream while the caller goes on with the backward pass); finish_buckets() waits and takes the mean."""
+        if world <= 1 and not force:
+            return
+        off, k = self.slices[index]
+        seg = self.flat_g[off:off + k]
+        if wire_dtype == torch.bfloat16 and k >= (1 << 20):
+            if getattr(self, "_wire", None) is None:
+                self._wire = torch.empty(self.n, dtype=torch.bfloat16, device=self.flat_g.device)
+            wire = self._wire[off:off + k]
+            check(lib().ast_cast(ptr(seg), 0, ptr(wire), 1, k, stream()), "ast_cast")
+            self._pending.append((dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True), seg, wire))
+        else:
+            self._pending.append((dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True), seg, None))
+
+    def finish_buckets(self, world):
+        pending, self._pending = self._pending, []
+        for work, seg, wire in pending:
+            work.wait()                                # the current stream waits for the collective (capturable)
+            if wire is not None:
+                check(lib().ast_cast(ptr(wire), 1, ptr(seg), 0, seg.numel(), stream()), "ast_cast")
+        if pending and world > 1:
+            check(lib().ast_scale(ptr(self.flat_g), None, 1.0 / world, ptr(self.flat_g), self.n, 0, stream()), "ast_scale")
 
     def adam(self, hyper, betas, eps, clip=True):
         """hyper: DEVICE tensor [lr, max_norm], read by the kernel at run time (a replayed graph follows an LR schedule).
@@ -175,15 +209,15 @@ class Trainer:
             nccl = dist.is_initialized() and dist.get_backend() == "nccl"
             wire = "bf16" if (config.compute_dtype == torch.bfloat16 and nccl) else "f32"
         self._wire_dtype = torch.bfloat16 if wire == "bf16" else torch.float32
-        self._matched = bool(self.cfg.loss_matched and world > 1)
+        self._force_coll = os.environ.get("AST_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
+        self._matched = bool(self.cfg.loss_matched and (world > 1 or self._force_coll))
         if self._matched:
-            ops.set_sync_bn(world)
-            self.cfg = dataclasses.replace(self.cfg, use_graph=False, multi_stream=False)
+            ops.set_sync_bn(world, force=self._force_coll)
+            self.cfg = dataclasses.replace(self.cfg, multi_stream=False, overlap_d=False)
         # Data parallel, default mode: the two gradient all-reduces are RCCL calls INSIDE the captured step (stream-ordered,
         # capturable through torch's NCCL process group), so world > 1 replays ONE graph with the discriminator phase
         # overlapped, exactly as one GPU does, instead of three graphs with eager collectives between them.  A probe
         # capture of a small all-reduce decides (any failure -> the three-graph form); AST_DIST_IN_GRAPH=0 turns it off.
-        self._force_coll = os.environ.get("AST_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
         self._dist = world > 1 or self._force_coll
         self._dist_in_graph = None                   # decided at the first graph step (probe)
         self._replicas_checked = False
@@ -256,7 +290,7 @@ class Trainer:
         elif self._matched:
             style_emb, _ = self.style(x, None)
             content_emb = self.content(x)
-            style_g = gather_rows(style_emb, self.rank, self.world)
+            style_g = gather_rows(style_emb, self.rank, self.world, force=self._force_coll)
             labels_g = global_labels(labels_host, self.world)
             class_emb = class_prototypes(style_g, labels_g)            # prototypes over the global batch
             self._glob = (style_g, labels_g)
@@ -283,7 +317,7 @@ class Trainer:
         style_b, labels_b, content_b = style_emb, labels_host, ops.mean_over_sections(content_emb)
         if self._matched:                    # batch-coupled terms on the gathered global batch
             style_b, labels_b = self._glob
-            content_b = gather_rows(content_b, self.rank, self.world)
+            content_b = gather_rows(content_b, self.rank, self.world, force=self._force_coll)
         if c.use_nce:
             nce = infoNCE_loss(style_b, labels_b)
             terms.append((H_W_NCE, nce))
@@ -298,7 +332,7 @@ class Trainer:
         # 6.2 ms -- with identical kernels (profiles/r03/bisect*.txt).
         return [(-1, ops.weighted_sum(self.hyper, terms))], parts
 
-    def _g_phase(self, x, y, labels_host, style_emb, class_emb, content_emb, before_adv=None, aux=None, side=None):
+    def _g_phase(self, x, y, labels_host, style_emb, class_emb, content_emb, before_adv=None, aux=None, side=None, mid=None):
         c = self.cfg
         cls_rows = ops.class_rows(class_emb, labels_host)
         if self._simple:
@@ -317,6 +351,8 @@ class Trainer:
             return g
 
         g_adv = None
+        if mid is not None:
+            mid()                         # (data parallel: D's gradient exchange + optimiser step, behind the decoder forward)
         if side is not None and aux is None:
             # The embedding losses and the generator's adversarial term run on the side stream (behind the D phase and D's
             # Adam step, which the adversarial term needs anyway).  They are created AFTER the decoder's nodes, so the
@@ -341,10 +377,33 @@ class Trainer:
             parts["adv_g"] = g_adv.detach()
         # total = w_rec rec + w_margin margin + w_nce nce + w_hsic hsic + w_adv adv_g, weights read from the device: one launch
         total = ops.weighted_sum(self.hyper, terms)
-        with layers_mod.parallel_flush():     # the three generator banks' gradient flushes side by side
-            total.backward()
+        if self._matched and c.bucketed and self._dist and not self._simple:
+            self._backward_bucketed(total, style_emb, content_emb)
+        else:
+            with layers_mod.parallel_flush():     # the three generator banks' gradient flushes side by side
+                total.backward()
         parts["total"] = total.detach()
         return parts
+
+    def _backward_bucketed(self, total, style_emb, content_emb):
+        """Backward pass in three stages, one gradient bucket each (loss-matched data parallel, one stream):
+          1. from the total down to the encoders' OUTPUTS and into every decoder parameter (the decoder's weight bank is flushed
+             by the end-of-backward callback of this stage) -> the decoder's slice of the flat gradient starts its all-reduce;
+          2. content encoder, from the gradient of its output -> its slice starts;  3. style encoder -> its slice.
+        The collectives run on the process group's stream while the next stage's kernels run on ours; G's optimiser step waits
+        for all three (FlatGroup.finish_buckets).  G's modules are [style, content, decoder]: slices 0, 1, 2."""
+        G = self.G
+        mods = (self.style, self.content, self.decoder)
+        par = [list(m.parameters()) for m in mods]
+        for t in (style_emb, content_emb):
+            t.retain_grad()
+        torch.autograd.backward(total, inputs=[style_emb, content_emb] + par[2])
+        G.all_reduce_bucket(2, self.world, self._wire_dtype, force=self._force_coll)
+        g_s, g_c = style_emb.grad, content_emb.grad
+        torch.autograd.backward([content_emb], [g_c], inputs=par[1])
+        G.all_reduce_bucket(1, self.world, self._wire_dtype, force=self._force_coll)
+        torch.autograd.backward([style_emb], [g_s], inputs=par[0])
+        G.all_reduce_bucket(0, self.world, self._wire_dtype, force=self._force_coll)
 
     # The step as three segments; the data-parallel gradient all-reduces sit between them.
     def _seg_a(self, x, labels_host):
@@ -400,16 +459,29 @@ class Trainer:
             self._stream_d = torch.cuda.Stream(device=self.device)
         sd = self._stream_d
         streams.fork(sd, main)
-        with torch.cuda.stream(sd):
-            d_loss = self._d_phase(style_emb, class_emb, content_emb, labels_host)
-            if self._dist:
-                self.D.all_reduce(self.world, force=self._force_coll)
+        def d_update():
             self.D.adam(self.hyper[H_LR_D:H_LR_D + 2], c.betas, c.eps, c.max_grad_norm > 0)
             self.D.zero_grad()
+        mid = None
+        with torch.cuda.stream(sd):
+            d_loss = self._d_phase(style_emb, class_emb, content_emb, labels_host)
+            if not self._dist:
+                d_update()
+        if self._dist:
+            # Data parallel: D's gradient all-reduce is issued from the capture's ORIGIN stream, after the decoder forward has been
+            # enqueued there (mid-way through _g_phase), and the side stream goes on from it.  RCCL's internal stream forks from
+            # and joins into the stream the collective is called on; called on the forked side stream that join would be "a forked
+            # stream waits on its own child" -- the pattern that crashes hipStreamEndCapture (streams.py).
+            def mid():
+                streams.join(main, sd)
+                self.D.all_reduce(self.world, force=self._force_coll)
+                streams.fork(sd, main)
+                with torch.cuda.stream(sd):
+                    d_update()
         d_loss.record_stream(main)
         # margin / InfoNCE / HSIC go to the side stream too, but are CREATED after the decoder's nodes (inside _g_phase):
         # created before them, their backward ran after the decoder's and held the three encoder branches back (+0.9 ms)
-        self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb, before_adv=lambda: streams.join(main, sd), side=sd)
+        self._parts = self._g_phase(x, y, labels_host, style_emb, class_emb, content_emb, before_adv=lambda: streams.join(main, sd), side=sd, mid=mid)
         self._parts["adv_d"] = d_loss.detach()
         if self._dist:
             self.G.all_reduce(self.world, self._wire_dtype, force=self._force_coll)
@@ -447,11 +519,13 @@ class Trainer:
 
     def _one_graph(self):
         """The step as ONE captured graph: a single GPU, or data parallel with the collectives inside the graph."""
-        if self.cfg.segmented or self._matched:
+        if self.cfg.segmented:
             return False
         if not self._dist:
             return self.world == 1
-        return bool(self._dist_in_graph) and self.cfg.multi_stream and self.cfg.overlap_d
+        # data parallel: the collectives must be capturable; the loss-matched mode is a single-stream step (its sync-BN and gather
+        # collectives cannot sit BETWEEN three graphs: without in-graph collectives it runs eagerly -- see step())
+        return bool(self._dist_in_graph) and ((self.cfg.multi_stream and self.cfg.overlap_d) or self._matched)
 
     def _probe_collective_capture(self):
         """Can this process group's all-reduce be captured into a hipGraph and replayed?  Decided once, by doing it on
@@ -494,7 +568,10 @@ class Trainer:
             self.D.all_reduce(self.world, force=self._force_coll)
         self._seg_b(x, labels_host)
         if self._dist:
-            self.G.all_reduce(self.world, self._wire_dtype, force=self._force_coll)
+            if self.G._pending:                # the bucketed exchange is already in flight (loss-matched mode)
+                self.G.finish_buckets(self.world)
+            else:
+                self.G.all_reduce(self.world, self._wire_dtype, force=self._force_coll)
         if self.cfg.keep_grads:
             self.last_grad_g = self.G.flat_g.clone()
         self._seg_c(x, labels_host)
@@ -553,8 +630,8 @@ class Trainer:
         assert not labels_host.is_cuda, "pass labels on the host: avoids a device sync per step"
         self._sync_hyper()
         if self._dist and self._dist_in_graph is None:
-            self._dist_in_graph = False if self._matched else self._probe_collective_capture()
-        if not self.cfg.use_graph:
+            self._dist_in_graph = self._probe_collective_capture()
+        if not self.cfg.use_graph or (self._matched and not self._dist_in_graph):
             self.losses = self._step_body(x, labels_host)
             return self.losses
         segmented = not self._one_graph()

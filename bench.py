@@ -309,6 +309,9 @@ def main():
     ap.add_argument("--mixed", action="store_true",
                     help="BASELINE configs[4]: a stream of 2..8 s clips, one length bucket per step (S = 1,1,2,2,2,3,3), audio-seconds counted "
                          "on the true clip lengths; replaces the fixed 4 s workload")
+    ap.add_argument("--per-rank-bn", action="store_true",
+                    help="N > 1: per-rank BatchNorm statistics and batch-coupled losses (valid DDP, NOT the single-process loss; multi-stream "
+                         "step) instead of the default loss-matched mode")
     ap.add_argument("--loss-matched", action="store_true",
                     help="N > 1: sync-BN + gathered batch-coupled losses (global-batch semantics, eager) instead of per-rank statistics")
     ap.add_argument("--decoder", default="new", choices=["new", "simple"],
@@ -342,6 +345,9 @@ def main():
     import ast_amd
     from ast_amd import train
     ast_amd.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    # N > 1 defaults to the loss-matched mode (sync-BN + gathered batch-coupled losses: the step of the single-process reference on
+    # the global batch, north_star "loss-matched"); --per-rank-bn selects the throughput mode
+    args.loss_matched = bool(args.loss_matched or (world > 1 and not args.per_rank_bn))
     tr = train.Trainer(train.TrainConfig(use_graph=not args.no_graph, loss_matched=args.loss_matched, decoder=args.decoder, multi_stream=not args.single_stream, overlap_d=not args.no_overlap_d), device=dev, rank=rank, world=world)
     clip_seconds = {1: 3.0, 2: CLIP_SECONDS, 3: 8.0, 4: 10.0}[args.sections]   # clip length that yields S sections
     if args.no_frontend:
@@ -394,8 +400,9 @@ def main():
                                   + ", all losses, D and G phases, grad clip, Adam",
                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": tr.cfg.use_graph,
                       "grad_allreduce": ("bf16" if tr._wire_dtype == torch.bfloat16 else "f32") if world > 1 else None,
-                      "collectives": (("captured inside the step's graph" if tr._dist_in_graph else "eager, between three graphs") if tr.cfg.use_graph else "eager") if world > 1 else None,
-                      "dp_semantics": ("global-batch (sync-BN + gathered losses)" if args.loss_matched and world > 1 else "per-rank BN and batch-coupled losses")},
+                      "collectives": (("captured inside the step's graph" if tr._dist_in_graph else ("eager step" if tr._matched else "eager, between three graphs")) if tr.cfg.use_graph else "eager") if world > 1 else None,
+                      "grad_exchange": ("three buckets (decoder, content, style) all-reduced while the backward pass goes on" if (tr._matched and tr.cfg.bucketed) else "one all-reduce per optimiser group after backward") if world > 1 else None,
+                      "dp_semantics": ("global-batch (sync-BN + gathered losses: loss-matched to the single-process step)" if args.loss_matched and world > 1 else "per-rank BN and batch-coupled losses")},
            "losses": losses}
     extras = rank == 0 and world == 1 and args.decoder == "new" and not args.no_extras
     if rank == 0 and world == 1 and args.infer and args.decoder == "new":

@@ -331,6 +331,11 @@ def test_mixed_length_stream_vs_oracle():
     assert len(tr._graphs) == 3                            # one capture per length bucket; revisits replay
 
 
+def ops_sync_active():
+    from ast_amd import ops
+    return ops._SyncBN.active
+
+
 def test_collectives_inside_the_captured_step_one_rank():
     """Data parallel, default mode: the two gradient all-reduces are RCCL calls captured INSIDE the step's graph (world > 1
     then replays one graph, like a single GPU).  One-rank rehearsal on this box: a 1-rank NCCL group, the collective path
@@ -354,7 +359,21 @@ def test_collectives_inside_the_captured_step_one_rank():
         # trainers differ by that much), and the collective path rounds the gradient to the bf16 wire
         for a, b in zip(losses, ref_losses):
             assert abs(a - b) <= 1e-2 * max(1.0, abs(b)), (losses, ref_losses)
+        # The LOSS-MATCHED mode on the same one-rank group (TrainConfig.loss_matched): the BatchNorm statistics all-reduces
+        # (forward and backward), the embedding gathers and the three-bucket gradient exchange -- ~70 small collectives -- are all
+        # captured inside ONE graph of a single-stream step; over one rank they are identities, so the losses must again follow the
+        # plain trainer.
+        trm = train.Trainer(train.TrainConfig(dropout=False, loss_matched=True), device="cuda:0")
+        assert trm._matched and not trm.cfg.multi_stream and ops_sync_active()
+        lm = [float(trm.step(x, labels)["total"]) for _ in range(3)]
+        assert trm._dist_in_graph is True
+        (graphs_m, _, _), = trm._graphs.values()
+        assert len(graphs_m) == 1
+        for a, b in zip(lm, ref_losses):
+            assert abs(a - b) <= 1e-2 * max(1.0, abs(b)), (lm, ref_losses)
     finally:
+        from ast_amd import ops as _ops
+        _ops.set_sync_bn(1)
         os.environ.pop("AST_FORCE_COLLECTIVES", None)
         dist.destroy_process_group()
 
