@@ -290,6 +290,12 @@ class Trainer:
         elif self._matched:
             style_emb, _ = self.style(x, None)
             content_emb = self.content(x)
+            # Stage boundaries of the bucketed backward pass (_backward_bucketed): everything downstream consumes VIEWS of the
+            # encoders' outputs.  backward(inputs=[t]) EXECUTES t's grad_fn (to fire its retain-grad hook) and then frees that
+            # node's saved tensors; for the raw outputs that node is the encoder's last layer, which the next stage still has to
+            # run.  A view's grad_fn is a ViewBackward: no kernel, nothing saved.
+            self._enc_raw = (style_emb, content_emb)
+            style_emb, content_emb = style_emb.view_as(style_emb), content_emb.view_as(content_emb)
             style_g = gather_rows(style_emb, self.rank, self.world, force=self._force_coll)
             labels_g = global_labels(labels_host, self.world)
             class_emb = class_prototypes(style_g, labels_g)            # prototypes over the global batch
@@ -397,13 +403,15 @@ class Trainer:
         par = [list(m.parameters()) for m in mods]
         for t in (style_emb, content_emb):
             t.retain_grad()
+        raw_s, raw_c = self._enc_raw                  # style_emb / content_emb are views of these (see _encoders)
         torch.autograd.backward(total, inputs=[style_emb, content_emb] + par[2])
         G.all_reduce_bucket(2, self.world, self._wire_dtype, force=self._force_coll)
         g_s, g_c = style_emb.grad, content_emb.grad
-        torch.autograd.backward([content_emb], [g_c], inputs=par[1])
+        torch.autograd.backward([raw_c], [g_c], inputs=par[1])
         G.all_reduce_bucket(1, self.world, self._wire_dtype, force=self._force_coll)
-        torch.autograd.backward([style_emb], [g_s], inputs=par[0])
+        torch.autograd.backward([raw_s], [g_s], inputs=par[0])
         G.all_reduce_bucket(0, self.world, self._wire_dtype, force=self._force_coll)
+        self._enc_raw = None
 
     # The step as three segments; the data-parallel gradient all-reduces sit between them.
     def _seg_a(self, x, labels_host):
