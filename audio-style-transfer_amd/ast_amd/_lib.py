@@ -113,6 +113,8 @@ _SIGS = {
     "ast_cqt_sections": ([vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "ast_resample_poly": ([vp, i32, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp], i32),
     "ast_wgrad_rep": ([vp, vp, vp, C.POINTER(Gather), i32, i32, vp], i32),
+    "ast_wgrad_slab": ([vp, vp, vp, C.POINTER(Gather), i32, i32, C.POINTER(i32), vp], i32),
+    "ast_slab_sum": ([C.POINTER(vp), C.POINTER(i64), C.POINTER(i32), i32, vp], i32),
     "ast_tok_max_ops": ([], i32),
     "ast_tok_program": ([vp, i32, i32, i32, vp, vp, vp, vp], i32),
 }

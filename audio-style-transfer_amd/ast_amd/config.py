@@ -47,3 +47,8 @@ wgrad_replicas = int(_os.environ.get("AST_WGRAD_REPLICAS", "8"))
 # 6.23 / 6.28 / 6.35 separate (profiles/r03/bisect6.txt) -- the table reduction in front of every apply workgroup costs what the
 # finalize launch cost, the 78 nodes it removes are worth ~0.1 ms of dispatch, and the sum is a wash.
 fused_finalize = _os.environ.get("AST_FUSED_FINALIZE", "0") != "0"
+
+# Slab flush of the pixel-rich conv layers' weight gradients (ast_wgrad_slab + ast_slab_sum): every pixel slice of a launch stores
+# its partial dW into its own copy (plain stores) and one launch per model sums the copies at the end of the backward pass, instead
+# of f32 atomics into 8 replicas.  Value = copies kept per small weight (also the cap on a launch's pixel slices); 0 = replicas.
+wgrad_slabs = int(_os.environ.get("AST_WGRAD_SLABS", "128"))

@@ -38,6 +38,7 @@ class WeightBank:
         self._pin_pool = None         # pinned host memory for those tables, allocated outside capture
         self._pin_used = 0
         self._conv_dirty = False
+        self._slab_recs = []          # (PackedWeight, pixel slices) of this backward pass's slab-mode weight gradients
         self.d_train = self.d_eval = None
         self._dev_consts = {}         # content -> device tensor (descriptor tables, tile lists): see _const_dev
         self._packed = {}             # (entry index, dtype, size) -> the entry's packed images and scratch
@@ -74,19 +75,25 @@ class WeightBank:
         # Small weights belong to the pixel-rich layers, whose weight-gradient kernels end with ~85 workgroups adding one tile
         # each into the same addresses (f32 atomics serialise: 14 us of a 40 us launch).  They get WGRAD_REPLICAS copies of
         # their staging; ast_wgrad_rep spreads the workgroups over them and the flush sums the copies.
-        sizes, reps = [], []
+        # With config.wgrad_slabs the small weights get that many copies instead and every pixel slice of the weight-gradient launch
+        # STORES into its own (ast_wgrad_slab); ast_slab_sum adds them into copy 0 in _flush, and the descriptor shows ONE copy.
+        sizes, reps, slabs = [], [], []
         for (w, kind, *_rest) in self.specs:
             if kind == "linear":
-                sizes.append(0); reps.append(1)
+                sizes.append(0); reps.append(1); slabs.append(False)
             else:
                 co, ci = (w.shape[0], w.shape[1]) if kind == "conv" else (w.shape[1], w.shape[0])
                 one = pad8(co) * w.shape[2] * w.shape[3] * pad8(ci)
-                r = config.wgrad_replicas if (config.wgrad_replicas > 1 and one <= (1 << 18)) else 1
-                sizes.append(one * r); reps.append(r)
-        if training and (getattr(self, "dw_arena", None) is None or self.dw_arena.device != dev):
+                small = one <= (1 << 18)
+                if small and config.wgrad_slabs > 1:
+                    r, sl = config.wgrad_slabs, True
+                else:
+                    r, sl = (config.wgrad_replicas if (config.wgrad_replicas > 1 and small) else 1), False
+                sizes.append(one * r); reps.append(r); slabs.append(sl)
+        if training and (getattr(self, "dw_arena", None) is None or self.dw_arena.device != dev or self.dw_arena.numel() < max(1, sum(sizes))):
             self.dw_arena = torch.zeros(max(1, sum(sizes)), dtype=torch.float32, device=dev)
         off = 0
-        for e, (w, kind, dtype_fn, u, v, bias, rows), sz, rep in zip(self.entries, self.specs, sizes, reps):
+        for e, (w, kind, dtype_fn, u, v, bias, rows), sz, rep, slab in zip(self.entries, self.specs, sizes, reps, slabs):
             dt = dtype_fn()
             if kind == "conv":
                 Co, Ci, k, _ = w.shape
@@ -117,7 +124,7 @@ class WeightBank:
             # inference session between two training steps must not invalidate the training descriptors
             grad_ptr = None
             if training:
-                e.dwp, e.replicas = None, rep
+                e.dwp, e.replicas, e.slab = None, rep, slab
                 if sz:
                     e.dwp = self.dw_arena[off:off + sz]
                     off += sz
@@ -125,7 +132,7 @@ class WeightBank:
             descs.append(WeightDesc(w=w.data_ptr() + 4 * w_off, u=ptr(u), v=ptr(v), sigma=ptr(e.sigma), scratch=ptr(e.scratch),
                                     wf=ptr(e.wf), wb=ptr(e.wb), Co=Co, Ci=Ci, KK=KK, s_co=s_co, s_ci=s_ci, Cop=e.Cop, Cip=e.Cip,
                                     power_iter=1 if training else 0, dwp=ptr(e.dwp), grad=grad_ptr, inner=ptr(e.gtmp),
-                                    dwp_from_wb=1 if kind == "convT" else 0, dwp_replicas=rep if training else 1))
+                                    dwp_from_wb=1 if kind == "convT" else 0, dwp_replicas=(1 if slab else rep) if training else 1))
             dts.append(dcode(dt))
             self.max_co = max(self.max_co, Co)
             self.max_cols = max(self.max_cols, Ci * KK)
@@ -168,6 +175,23 @@ class WeightBank:
         self._lin_deferred.append((pw, dy, x))
         self.request_flush(conv=False)
 
+    def note_slab(self, pw, slices):
+        if any(p is pw for p, _ in self._slab_recs):
+            raise NotImplementedError("a convolution weight was used twice in one backward pass: its slab-mode gradient does not "
+                                      "accumulate (set AST_WGRAD_SLABS=0 for the atomic replicas)")
+        self._slab_recs.append((pw, slices))
+
+    def _sum_slabs(self):
+        """copy 0 <- sum of the slices' copies, for all slab-mode weights of this backward pass, 48 weights per launch"""
+        recs, self._slab_recs = self._slab_recs, []
+        for i in range(0, len(recs), 48):
+            part = recs[i:i + 48]
+            n = len(part)
+            bases = (C.c_void_p * n)(*[pw.dwp.data_ptr() for pw, _ in part])
+            sizes = (C.c_int64 * n)(*[pw.dwp.numel() // pw.replicas for pw, _ in part])
+            slabs = (C.c_int32 * n)(*[sl for _, sl in part])
+            check(lib().ast_slab_sum(bases, sizes, slabs, n, stream()), "ast_slab_sum")
+
     def request_flush(self, conv=True):
         self._conv_dirty = self._conv_dirty or conv
         if not self._flush_pending:
@@ -191,6 +215,8 @@ class WeightBank:
                 streams.fork(side, torch.cuda.current_stream())
                 _ParallelFlush.pending.append(side)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                if self._slab_recs:
+                    self._sum_slabs()
                 check(lib().ast_weight_grads_flush_t(ptr(self.d_train), ptr(self.d_tiles), self.ntiles, stream()),
                       "ast_weight_grads_flush_t")
         if self._lin_deferred:

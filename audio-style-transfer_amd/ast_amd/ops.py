@@ -213,11 +213,16 @@ def _igemm(src, wgt, bias, dst, g, flags=0, stats=None, bn=None, per_image=False
         PROFILE.append((f"igemm_kernel<{dt},{_igemm_config(g, dcode(src.dtype))}>", fl, by, e0, e1))
 
 
-def _wgrad(dy, src, dwp, g, replicas=1):
+def _wgrad(dy, src, dwp, g, replicas=1, pw=None):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if replicas > 1:                               # dwp holds `replicas` zeroed copies; the bank's flush sums them
+    if pw is not None and pw.slab:                 # dwp holds `replicas` copies: one per pixel slice, plain stores; the bank sums them
+        import ctypes
+        slices = ctypes.c_int32(0)
+        check(lib().ast_wgrad_slab(ptr(dy), ptr(src), ptr(dwp), g, dcode(src.dtype), int(replicas), ctypes.byref(slices), stream()), "ast_wgrad_slab")
+        pw.bank.note_slab(pw, int(slices.value))
+    elif replicas > 1:                             # dwp holds `replicas` zeroed copies; the bank's flush sums them
         check(lib().ast_wgrad_rep(ptr(dy), ptr(src), ptr(dwp), g, dcode(src.dtype), int(replicas), stream()), "ast_wgrad_rep")
     else:
         check(lib().ast_wgrad(ptr(dy), ptr(src), ptr(dwp), g, dcode(src.dtype), stream()), "ast_wgrad")
@@ -240,11 +245,12 @@ class PackedWeight:
     """One GEMM weight of a model: the f32 master parameter (PyTorch layout),
     optional spectral-norm buffers and its two packed images (see WeightBank)."""
     __slots__ = ("weight", "u", "v", "bias", "Co", "Ci", "KK", "s_co", "s_ci", "Cop", "Cip", "dtype", "wf", "wb",
-                 "sigma", "scratch", "bias_pad", "w_off", "b_off", "transposed", "gtmp", "dwp", "bank", "replicas")
+                 "sigma", "scratch", "bias_pad", "w_off", "b_off", "transposed", "gtmp", "dwp", "bank", "replicas", "slab")
 
     def __init__(self):
         self.wf = self.wb = self.dwp = self.bank = None
         self.replicas = 1
+        self.slab = False
 
     def bias_ptr_tensor(self):
         if self.bias is None:
@@ -295,7 +301,7 @@ class Conv2dFn(torch.autograd.Function):
         N, H, W, Cs = x.shape
         if pw.dwp is None:
             raise RuntimeError("weights were prepared in eval/no-grad mode; run the forward in training mode before backward")
-        _wgrad(dy, x, pw.dwp, ctx.geom, pw.replicas)           # into the per-model staging arena; unpacked once after backward
+        _wgrad(dy, x, pw.dwp, ctx.geom, pw.replicas, pw)           # into the per-model staging arena; unpacked once after backward
         pw.bank.request_flush()
         if ctx.bias_grad:
             pw.add_bias_grad(dy)
@@ -351,8 +357,8 @@ class ResHeadFn(torch.autograd.Function):
         N, H, W, Cs = x.shape
         if pw1.dwp is None or pwd.dwp is None:
             raise RuntimeError("weights were prepared in eval/no-grad mode; run the forward in training mode before backward")
-        _wgrad(dc1, x, pw1.dwp, g1, pw1.replicas)
-        _wgrad(didn, x, pwd.dwp, gd, pwd.replicas)
+        _wgrad(dc1, x, pw1.dwp, g1, pw1.replicas, pw1)
+        _wgrad(didn, x, pwd.dwp, gd, pwd.replicas, pwd)
         pw1.bank.request_flush()                 # both convs feed a normalisation: their biases carry no gradient
         dx = None
         if ctx.needs_input_grad[0]:
@@ -393,7 +399,7 @@ class ConvT2dFn(torch.autograd.Function):
         assert (Hx, Wx) == (H, W), "ConvTranspose2d geometry mismatch"
         if pw.dwp is None:
             raise RuntimeError("weights were prepared in eval/no-grad mode; run the forward in training mode before backward")
-        _wgrad(x, dy, pw.dwp, g, pw.replicas)
+        _wgrad(x, dy, pw.dwp, g, pw.replicas, pw)
         pw.bank.request_flush()
         if ctx.bias_grad:
             pw.add_bias_grad(dy)

@@ -32,12 +32,14 @@ __device__ long long ast_wg_phase[4096 * 4];                // K-loop sub-phases
 // 4 x 64 B shape measured 0.87 TB/s of added bytes here against ~1.3 TB/s): the tile goes through LDS (free at this point) and
 // every wave adds whole 64-float row segments -- 64 consecutive (tap, channel) columns of one output channel = 256 contiguous
 // bytes when the source has >= 64 channels, two 128-byte runs for 32.  Ends with every thread of the (remaining) workgroup.
+// mode 0: atomics from the registers (default), 1: atomics in 256-byte rows through LDS, 2: PLAIN STORES in 256-byte rows through LDS
+// (slab mode: the pixel slice owns its copy of dW -- ast_wgrad_slab -- so nothing else adds to these addresses in this launch).
 template <int BMW, int NCT, int RT, int CTW, typename WtOf>
 __device__ __forceinline__ void flush_tile_rows(const f32x4 (&acc)[RT][CTW], float* tile, float* dw, const ast_gather_t& g, const int cd0,
-                                                const int col0, const int ncols, const int wave, const int lane, WtOf wt_of, const bool direct) {
+                                                const int col0, const int ncols, const int wave, const int lane, WtOf wt_of, const int mode) {
   constexpr int BNW = NCT * 16;
   const int li = lane & 15, gq = lane >> 4;
-  if (direct) {                                      // A/B (AST_WGRAD_FLUSH_LDS=0): atomics straight from the accumulator registers
+  if (mode == 0) {                                      // A/B (AST_WGRAD_FLUSH_LDS=0): atomics straight from the accumulator registers
 #pragma unroll
     for (int j = 0; j < CTW; ++j) {
       const int ct = wave + 4 * j;
@@ -73,9 +75,16 @@ __device__ __forceinline__ void flush_tile_rows(const f32x4 (&acc)[RT][CTW], flo
     if (col >= ncols) continue;
     const int t = col / g.Cs, c = col - t * g.Cs;
     float* dcol = dw + (size_t)wt_of(t) * g.Cs + c;
-    for (int row = wave; row < BMW; row += 4) {
-      const int cd = cd0 + row;
-      if (cd < g.Cd) unsafeAtomicAdd(dcol + (size_t)cd * g.wtaps * g.Cs, tile[row * BNW + cc * 64 + lane]);
+    if (mode == 2) {
+      for (int row = wave; row < BMW; row += 4) {
+        const int cd = cd0 + row;
+        if (cd < g.Cd) dcol[(size_t)cd * g.wtaps * g.Cs] = tile[row * BNW + cc * 64 + lane];
+      }
+    } else {
+      for (int row = wave; row < BMW; row += 4) {
+        const int cd = cd0 + row;
+        if (cd < g.Cd) unsafeAtomicAdd(dcol + (size_t)cd * g.wtaps * g.Cs, tile[row * BNW + cc * 64 + lane]);
+      }
     }
   }
 }
@@ -85,6 +94,9 @@ __device__ __forceinline__ void flush_tile_rows(const f32x4 (&acc)[RT][CTW], flo
 // 42.2, 256: 41.8 -> 43.3; profiles/r03/wg_flush.txt): at ~11 adders per address the 4 x 64 B shape is not what bounds the flush.
 inline bool wg_flush_direct() { const char* e = getenv("AST_WGRAD_FLUSH_LDS"); return !(e && atoi(e) != 0); }
 static thread_local int g_wg_nrep = 1;
+static thread_local int g_wg_slab = 0;            // ast_wgrad_slab: g_wg_nrep slabs, one per pixel slice, plain stores
+static thread_local int g_wg_slices = 0;          // out: pixel slices of the last launch
+inline int wg_nrep_arg() { return g_wg_nrep | ((g_wg_slab ? 2 : (wg_flush_direct() ? 0 : 1)) << 16); }
 static thread_local long g_wg_rep_stride = 0;
 template <typename T> struct WgradCfg;
 template <> struct WgradCfg<bf16_t> { static constexpr int BKP = 64, PAD = 16; };   // elements: row pitch = 32 B x odd for rows that are multiples of 64 B (see SWZ)
@@ -297,9 +309,9 @@ __global__ __launch_bounds__(256 * PG) void wgrad_kernel(const T* __restrict__ d
     if (pg > 0) return;
   }
   WG_STAMP(3);
-  dw += (size_t)(bz % (nrep < 0 ? -nrep : nrep)) * rep_stride;          // this pixel slice's gradient replica (sign of nrep: flush A/B switch)
+  dw += (size_t)(bz % (nrep & 0xffff)) * rep_stride;          // this pixel slice's gradient replica / slab (nrep bits 16-17: flush mode)
   flush_tile_rows<BMW, NCT, RT, CTW>(acc, reinterpret_cast<float*>(wl_all), dw, g, cd0, col0, ncols, wave, lane,
-                                     [&](int t) { return taptab[t] >> 16; }, nrep < 0);
+                                     [&](int t) { return taptab[t] >> 16; }, (nrep >> 16) & 3);
 #ifdef AST_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the atomics have been acknowledged
 #endif
@@ -332,14 +344,16 @@ int launch_wgrad_pg(const void* dy, const void* src, float* dw, const ast_gather
   // average in the replayed step (tools/knob_ab.sh; 320: 29.1, 448: 30.5), the two-group and the narrow ones do not (32.7 -> 43.3)
   const int wg_target = wte ? atoi(wte) : (P >= 1500000 ? 768 : (PG == 1 && NCT >= 12 ? 384 : 256));
   int nsplit = std::max(1, std::min((P + 4 * BKP - 1) / (4 * BKP), (wg_target + tiles - 1) / tiles));
+  if (g_wg_slab) nsplit = std::min(nsplit, g_wg_nrep);         // slab mode: one copy of dW per pixel slice
   int pps = (P + nsplit - 1) / nsplit;
   pps = (pps + BKP - 1) / BKP * BKP;
   nsplit = (P + pps - 1) / pps;
   const unsigned dy_bytes = (unsigned)((size_t)P * g.Cd * sizeof(T));
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
   const int total = gx * gy * nsplit;
+  g_wg_slices = nsplit;
   hipLaunchKernelGGL((wgrad_kernel<T, BMW, NCT, PG>), dim3((total + 7) / 8 * 8), dim3(256 * PG), LDS, s, (const T*)dy, (const T*)src, dw, g, P, pps,
-                     dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm, gx, gy, nsplit, wg_flush_direct() ? -g_wg_nrep : g_wg_nrep, g_wg_rep_stride);
+                     dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm, gx, gy, nsplit, wg_nrep_arg(), g_wg_rep_stride);
   AST_CHECK_LAUNCH();
   return 0;
 }
@@ -566,9 +580,9 @@ __global__ __launch_bounds__(256 * PG) void wgrad_halo_kernel(const T* __restric
     }
     if (pg > 0) return;
   }
-  dw += (size_t)(blockIdx.z % (nrep < 0 ? -nrep : nrep)) * rep_stride;      // this slice's gradient replica (see g_wg_nrep)
+  dw += (size_t)(blockIdx.z % (nrep & 0xffff)) * rep_stride;      // this slice's gradient replica / slab (see g_wg_nrep)
   flush_tile_rows<BMW, NCT, RT, CTW>(acc, reinterpret_cast<float*>(wl_all), dw, g, cd0, col0, ncols, wave, lane,
-                                     [&](int t) { return taptab[16 + t]; }, nrep < 0);
+                                     [&](int t) { return taptab[16 + t]; }, (nrep >> 16) & 3);
 }
 
 bool plan_wgrad_halo(const ast_gather_t& g, int dtype, int nct, int bmw, WHaloPlan& hp) {
@@ -608,11 +622,13 @@ int launch_wgrad_halo_pg(const void* dy, const void* src, float* dw, const ast_g
   // stays at about one per CU and the waves come from the pixel groups (sweep in profiles/r01 and r02)
   const char* wt = getenv("AST_WGRAD_WG_TARGET");
   const int wg_target = wt ? atoi(wt) : (PG > 1 ? 256 : ((long)g.N * g.Hm * g.Wm >= 1500000 ? 768 : 256));
-  const int gz = std::max(1, std::min((hp.ntiles + PG - 1) / PG, wg_target / (gx * gy)));
+  int gz = std::max(1, std::min((hp.ntiles + PG - 1) / PG, wg_target / (gx * gy)));
+  if (g_wg_slab) gz = std::min(gz, g_wg_nrep);
+  g_wg_slices = gz;
   const unsigned dy_bytes = (unsigned)((size_t)g.N * g.Hm * g.Wm * g.Cd * sizeof(T));
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
   hipLaunchKernelGGL((wgrad_halo_kernel<T, BMW, NCT, PG>), dim3(gx, gy, gz), dim3(256 * PG), lds, s, (const T*)dy, (const T*)src, dw, g, hp,
-                     dy_bytes, src_bytes, wg_flush_direct() ? -g_wg_nrep : g_wg_nrep, g_wg_rep_stride);
+                     dy_bytes, src_bytes, wg_nrep_arg(), g_wg_rep_stride);
   AST_CHECK_LAUNCH();
   return 0;
 }
@@ -848,6 +864,7 @@ int launch_wgrad_tap(const void* dy, const void* src, float* dw, const ast_gathe
   const unsigned dy_bytes = (unsigned)((size_t)P * g.Cd * sizeof(T));
   const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * sizeof(T));
   const int total = tiles * gz;
+  g_wg_slices = gz;
   hipLaunchKernelGGL((wgrad_tap_kernel<T, NW>), dim3((total + 7) / 8 * 8), dim3(64 * NW), LDS, s, (const T*)dy, (const T*)src, dw, g, P, pps,
                      dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm, gx, gy, gz, g_wg_nrep, g_wg_rep_stride, gz == 1 ? 1 : 0);
   AST_CHECK_LAUNCH();
@@ -864,6 +881,71 @@ extern "C" int ast_wgrad_rep(const void* dy, const void* src, float* dw, const a
   const int rc = ast_wgrad(dy, src, dw, gp, dtype, stream);
   g_wg_nrep = 1; g_wg_rep_stride = 0;
   return rc;
+}
+
+// ---- slab mode: every pixel slice STORES its partial dW into its own copy; ast_slab_sum adds the copies up ----------------------
+// The atomic flush of the pixel-rich layers is rate-bound, not contention-bound: slices x |dW| bytes of f32 atomics at the chip's
+// ~1.3 TB/s (measured here: 0.19 us per slice of the 147 KB gradient = 0.77 TB/s; tools/halo_probe.sh: time = trips x 1.6 us +
+// slices x 0.19 us), a third to a half of the launch.  Plain 256-byte-row stores move the same bytes at the HBM rate.
+namespace {
+struct SlabRec { float* base; unsigned n, slabs; };                    // n floats per copy, copies n floats apart
+struct SlabArgs { SlabRec rec[AST_MAX_SLAB_RECS]; unsigned first_block[AST_MAX_SLAB_RECS + 1]; int nrec; };
+// copy 0 <- sum of the `slabs` copies; a workgroup owns 1024 consecutive floats of one record, eight copies in flight per thread
+__global__ __launch_bounds__(256) void slab_sum_kernel(const SlabArgs a) {
+  int r = 0;
+#pragma unroll 1
+  while (r + 1 < a.nrec && blockIdx.x >= a.first_block[r + 1]) ++r;
+  // (scalar selects, not a dynamic index into the by-value struct: that would put it in scratch memory)
+  float* base = nullptr; unsigned n = 0, slabs = 0, fb = 0;
+#pragma unroll
+  for (int i = 0; i < AST_MAX_SLAB_RECS; ++i)
+    if (i == r) { base = a.rec[i].base; n = a.rec[i].n; slabs = a.rec[i].slabs; fb = a.first_block[i]; }
+  const unsigned i4 = ((blockIdx.x - fb) * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(base + i4);
+  unsigned s = 1;
+  for (; s + 8 <= slabs; s += 8) {
+    f32x4 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4*>(base + (size_t)(s + k) * n + i4);
+    acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+  }
+  for (; s < slabs; ++s) acc += *reinterpret_cast<const f32x4*>(base + (size_t)s * n + i4);
+  *reinterpret_cast<f32x4*>(base + i4) = acc;
+}
+}  // namespace
+
+extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t* gp, int dtype, void* stream);
+extern "C" int ast_wgrad_slab(const void* dy, const void* src, float* slabs, const ast_gather_t* gp, int dtype, int nslabs, int* slices_out,
+                              void* stream) {
+  if (nslabs < 1 || nslabs > 4096 || !gp || !slices_out) AST_FAIL("ast_wgrad_slab: 1..4096 slabs and a slices output");
+  g_wg_nrep = nslabs; g_wg_slab = 1; g_wg_slices = 0;
+  g_wg_rep_stride = (long)gp->Cd * gp->wtaps * gp->Cs;
+  const int rc = ast_wgrad(dy, src, slabs, gp, dtype, stream);
+  *slices_out = g_wg_slices;
+  g_wg_nrep = 1; g_wg_slab = 0; g_wg_rep_stride = 0;
+  return rc;
+}
+
+extern "C" int ast_slab_sum(float* const* bases, const int64_t* floats_per_copy, const int* slabs, int nrec, void* stream) {
+  if (!bases || !floats_per_copy || !slabs || nrec < 1 || nrec > AST_MAX_SLAB_RECS) AST_FAIL("ast_slab_sum: 1..%d records", AST_MAX_SLAB_RECS);
+  SlabArgs a;
+  unsigned blocks = 0;
+  a.nrec = nrec;
+  for (int i = 0; i < AST_MAX_SLAB_RECS; ++i) {
+    a.rec[i] = SlabRec{nullptr, 0, 0};
+    a.first_block[i] = blocks;
+    if (i < nrec) {
+      if (!bases[i] || floats_per_copy[i] < 4 || (floats_per_copy[i] & 3) || floats_per_copy[i] > (1L << 30) || slabs[i] < 1 || (((uintptr_t)bases[i]) & 15))
+        AST_FAIL("ast_slab_sum: record %d: 16-byte aligned base, a multiple of 4 floats per copy, >= 1 copies", i);
+      a.rec[i] = SlabRec{bases[i], (unsigned)floats_per_copy[i], (unsigned)slabs[i]};
+      blocks += (unsigned)((floats_per_copy[i] + 1023) / 1024);
+    }
+  }
+  a.first_block[AST_MAX_SLAB_RECS] = blocks;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  AST_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t* gp, int dtype, void* stream) {
@@ -887,7 +969,7 @@ extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_g
   // fabric, not the MFMAs), and a workgroup takes a whole CU (128 KB of LDS) away from the other streams' kernels.  DESIGN 9.3.
   const char* te = getenv("AST_WGRAD_TAP");                  // read per call (host side only): tests toggle it at run time
   const bool tap_on = te && atoi(te) != 0;
-  if (tap_on && g.Cd >= 64) { AST_DISPATCH_T(dtype, { return launch_wgrad_tap<T>(dy, src, dw, g, P, s); }); }
+  if (tap_on && !g_wg_slab && g.Cd >= 64) { AST_DISPATCH_T(dtype, { return launch_wgrad_tap<T>(dy, src, dw, g, P, s); }); }
   WHaloPlan whp;
   const bool halo = plan_wgrad_halo(g, dtype, nct, bmw, whp);
 #define AST_WG(B_, N_) do { if (halo) return launch_wgrad_halo<T, B_, N_>(dy, src, dw, g, whp, s); \

@@ -88,6 +88,15 @@ int ast_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t* g,
  * use copy z % nrep): same-address f32 atomics serialise, and the reader (ast_weight_grads_flush_t with
  * ast_weight_desc_t.dwp_replicas) sums the copies.  All copies must be zeroed by the caller. */
 int ast_wgrad_rep(const void* dy, const void* src, float* dw, const ast_gather_t* g, int dtype, int nrep, void* stream);
+/* Slab form of the same: the launch cuts the pixels into at most `nslabs` slices, and every slice STORES (plain 256-byte-row
+ * stores, no atomics) its partial gradient into its own copy of dW -- slabs[z * Cd*wtaps*Cs ...] for slice z; *slices_out = the
+ * number of copies written (every one of them completely: nothing needs to be zeroed first).  ast_slab_sum adds the copies up:
+ * copy 0 <- sum of the first slabs[i] copies of record i, for up to AST_MAX_SLAB_RECS weights in ONE launch (bases / floats_per_copy /
+ * slabs are HOST arrays).  NOT an accumulate: a weight used twice in one backward pass must use ast_wgrad / ast_wgrad_rep. */
+#define AST_MAX_SLAB_RECS 48
+int ast_wgrad_slab(const void* dy, const void* src, float* slabs, const ast_gather_t* g, int dtype, int nslabs, int* slices_out,
+                   void* stream);
+int ast_slab_sum(float* const* bases, const int64_t* floats_per_copy, const int* slabs, int nrec, void* stream);
 
 /* Token-sized nn.Linear (M <= 64 rows, f32): y = act(x W^T + b), W row pitch ldw (W may be a row slice
  * of in_proj_weight or the transposed pack for the data gradient).  One wave per output column. */

@@ -228,6 +228,38 @@ def test_wgrad_replicas_sum_to_the_gradient(dtype, cin, cout, k, stride, H, W, N
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,N", [(32, 32, 3, 1, 40, 61, 4), (8, 32, 3, 2, 64, 97, 4), (64, 64, 3, 1, 30, 50, 4), (32, 64, 1, 2, 40, 60, 2),
+                                                     (64, 128, 3, 2, 36, 75, 3), (2, 16, 3, 1, 57, 83, 2)])
+def test_wgrad_slab_store_and_sum(dtype, cin, cout, k, stride, H, W, N):
+    """ast_wgrad_slab: every pixel slice STORES its partial gradient into its own copy of dW (no atomics); ast_slab_sum adds the
+    copies into copy 0.  The copies start as NaN: a slice that left any element of its copy unwritten would poison the sum."""
+    import ctypes
+    from ast_amd._lib import check, dcode, lib, ptr, stream
+    config.set_compute_dtype(dtype)
+    torch.manual_seed(6)
+    cin_p, cout_p = ops.pad8(cin), ops.pad8(cout)
+    g, (Ho, Wo) = ops.gather_direct(N, H, W, cin_p, cout_p, k, stride, 1 if k == 3 else 0)
+    x = torch.randn(N, H, W, cin_p, device=DEV).to(dtype)
+    dy = torch.randn(N, Ho, Wo, cout_p, device=DEV).to(dtype)
+    one = torch.zeros(cout_p, k * k, cin_p, device=DEV)
+    check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(one), g, dcode(dtype), stream()), "ast_wgrad")
+    n = one.numel()
+    for nslabs in (3, 128):
+        slabs = torch.full((nslabs, n), float("nan"), device=DEV)
+        slices = ctypes.c_int32(0)
+        check(lib().ast_wgrad_slab(ptr(dy), ptr(x), ptr(slabs), g, dcode(dtype), nslabs, ctypes.byref(slices), stream()), "ast_wgrad_slab")
+        sl = int(slices.value)
+        assert 1 <= sl <= nslabs
+        bases, sizes, cnt = (ctypes.c_void_p * 1)(slabs.data_ptr()), (ctypes.c_int64 * 1)(n), (ctypes.c_int32 * 1)(sl)
+        check(lib().ast_slab_sum(bases, sizes, cnt, 1, stream()), "ast_slab_sum")
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(slabs[:sl]).all()), "a pixel slice left part of its copy unwritten"
+        assert rel_err(slabs[0].view_as(one), one) < 2e-5, (nslabs, sl)
+        if sl < nslabs:
+            assert bool(torch.isnan(slabs[sl:]).all())                     # copies beyond the slices are never touched
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout,k,stride,H,W,N", [
     (64, 64, 3, 1, 30, 50, 4),       # one tap per 64-column tile, several pixel slices (atomic flush)
     (32, 64, 3, 2, 37, 53, 3),       # two taps per column tile, stride 2, odd sizes, last column tile half empty
