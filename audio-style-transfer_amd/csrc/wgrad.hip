@@ -358,6 +358,200 @@ int launch_wgrad_pg(const void* dy, const void* src, float* dw, const ast_gather
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// wgrad_ring_kernel (bf16): the same contraction, operand staging and MFMA fragments as wgrad_kernel<bf16, 64, NCT, 1>, with the K
+// loop rebuilt around the one thing the round-3 probe blamed (tools/halo_probe.sh: launch time = trips x 1.6 us + slices x flush):
+// a 64-pixel trip of the register-staged loop costs ~3 600 cycles for 384 cycles of MFMA because the NEXT tile's loads are
+// issued only after this tile has been stored, so every trip waits out a full memory round trip with one workgroup on the CU.
+// Here the operands travel by LDS-DMA (buffer_load_dwordx4 ... lds: global memory -> LDS, no VGPRs, no ds_write) into a RING of
+// four stages: at trip t the tiles t+1, t+2 and (just issued) t+3 are in flight, the wave waits with a COUNTED s_waitcnt vmcnt
+// for tile t only, one raw s_barrier per trip makes every wave's pieces of tile t visible (and says that stage (t+3) % 4, read in
+// trip t-1, is free), then transposed reads + MFMAs.
+// LDS-DMA writes wave-uniform base + lane x 16 B, so the image is cut into PIECES of 16 pixel rows x 64 B that one wave-instruction
+// fills linearly: stage = [column block j][pixel row r][64 B], block j = columns 32j..32j+31 (bf16).  Wave w owns rows 16w..16w+15
+// of every block: a lane keeps ONE pixel row for the whole launch (one pixel decode per tile, as before).  A transposed read of a
+// half-wave touches rows {q, q+8} x 32 B of one block at a 64-byte pitch; the 32-byte half h of row r is stored at h ^ ((r >> 3) & 1)
+// -- applied on the SOURCE side (which chunk a lane fetches), the LDS side stays linear -- and the 32 lanes fall on 64 distinct banks.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int NCT>
+__global__ __launch_bounds__(256) void wgrad_ring_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ src, float* __restrict__ dw,
+                                                         const ast_gather_t g, const int P, const int pps, const unsigned dy_bytes,
+                                                         const unsigned src_bytes, const float rcp_hw, const float rcp_w, const int gx,
+                                                         const int gy, const int gz, const int nrep, const long rep_stride) {
+  constexpr int BMW = 64, BKP = 64, E = 8, ES = 2;
+  constexpr int BNW = NCT * 16;
+  constexpr int YB = 2, XB = NCT / 2;               // 64-byte column blocks of the dy / source images
+  constexpr int BLK = BKP * 64;                     // bytes of one block: 64 pixel rows x 64 B
+  constexpr int STAGE = (YB + XB) * BLK;
+  constexpr int NST = 4;
+  constexpr int NDMA = YB + XB;                     // LDS-DMA instructions per wave and tile
+  constexpr int RT = BMW / 16, CTW = (NCT + 3) / 4;
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(NCT % 4 == 0 && NDMA * 3 <= 63 && BKP == 64, "tile");
+  extern __shared__ __attribute__((aligned(16))) unsigned char wr_all[];
+  int* taptab = reinterpret_cast<int*>(wr_all + NST * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = gridDim.x >> 3;                 // XCD-aware order, as wgrad_kernel
+  const int tix = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tix >= gx * gy * gz) return;
+  const int bx = tix / (gz * gy), bz = (tix / gy) % gz, by = tix % gy;
+  const int cd0 = bx * BMW, col0 = by * BNW;
+  const int ncols = g.ntaps * g.Cs;
+  const int HWm = g.Hm * g.Wm;
+  const int p_begin = bz * pps, p_end = min(P, p_begin + pps);
+  const __amdgpu_buffer_rsrc_t dyR = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srcR = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, src_bytes, 0x00020000);
+#pragma unroll
+  for (int t = 0; t < AST_MAX_TAPS; ++t)
+    if (tid == t) taptab[t] = g.tap[t];
+  __syncthreads();
+
+  // loader role: pixel row lrow of the tile, 16-byte chunk q of every 64-byte block; the chunk FETCHED for LDS position q is the
+  // one whose 32-byte half is h ^ ((lrow >> 3) & 1)
+  const int lrow = tid >> 2, q = tid & 3;
+  const int dq = ((((q >> 1) ^ ((lrow >> 3) & 1)) & 1) << 1) | (q & 1);       // data chunk inside the block
+  int ycd[YB];                                      // channel of the lane's dy chunk per block (>= Cd: no such channel)
+#pragma unroll
+  for (int j = 0; j < YB; ++j) ycd[j] = cd0 + (4 * j + dq) * E;
+  int xdelta[XB], xdh[XB], xdw[XB];                 // per source block: byte delta of (tap, channel), tap offsets; dh = 1 << 20: no column
+#pragma unroll
+  for (int j = 0; j < XB; ++j) {
+    const int col = col0 + (4 * j + dq) * E;
+    xdelta[j] = 0; xdh[j] = 1 << 20; xdw[j] = 0;
+    if (col < ncols) {
+      const int t = col / g.Cs, c = col - t * g.Cs;
+      int dh, dw_, wt;
+      decode_tap(taptab[t], dh, dw_, wt);
+      xdh[j] = dh; xdw[j] = dw_;
+      xdelta[j] = ((dh * g.Ws + dw_) * g.Cs + c) * ES;
+    }
+  }
+  auto issue_tile = [&](int kt) __attribute__((always_inline)) {
+    unsigned char* st = wr_all + (kt & (NST - 1)) * STAGE + wave * 1024;      // this wave's 16 rows of block 0 (wave-uniform)
+    const int p = p_begin + kt * BKP + lrow;
+    const bool pv = p < p_end;
+    const int pp = pv ? p : 0;
+#pragma unroll
+    for (int j = 0; j < YB; ++j) {
+      const bool ok = pv && ycd[j] < g.Cd;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dyR, (lds_void_t*)(st + j * BLK), 16, ok ? (unsigned)((pp * g.Cd + ycd[j]) * ES) : OOB, 0, 0, 0);
+    }
+    const int n = fdiv(pp, HWm, rcp_hw), rem = pp - n * HWm;
+    const int hm = fdiv(rem, g.Wm, rcp_w), wq = rem - hm * g.Wm;
+    const int hs0 = pv ? hm * g.sh + g.oh : -(1 << 21), ws0 = wq * g.sw + g.ow;
+    const int base = (((n * g.Hs + hs0) * g.Ws + ws0) * g.Cs) * ES;
+#pragma unroll
+    for (int j = 0; j < XB; ++j) {
+      const bool ok = (unsigned)(hs0 + xdh[j]) < (unsigned)g.Hs && (unsigned)(ws0 + xdw[j]) < (unsigned)g.Ws;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcR, (lds_void_t*)(st + (YB + j) * BLK), 16, ok ? (unsigned)(base + xdelta[j]) : OOB, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[RT][CTW];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int li = lane & 15, gq = lane >> 4;
+  const int nk = (p_end - p_begin + BKP - 1) / BKP;
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nk) issue_tile(t);
+  // The transposed reads are INLINE ASSEMBLY with hand-placed s_waitcnt lgkmcnt: the compiler treats every LDS-DMA in flight as a
+  // possible writer of whatever a ds_read it can see reads and puts s_waitcnt vmcnt(0) in front of it -- which would wait for the
+  // tile issued a moment ago and serialise the ring.  (Stage separation is by ring index, which no alias analysis sees.)
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)wr_all;
+  const unsigned rd0 = lds0 + (8 * gq + (li >> 2)) * 64 + (li & 3) * 8;      // row r_lo of k-step 0, chunk of this lane, half 0
+  const unsigned hx = (gq & 1) << 5;                                         // rows r_lo and r_lo + 4 share bit 3 (= gq & 1)
+  unsigned aoff[RT], boff[CTW];                                              // byte offsets of the lane's A / B fragments inside a stage
+#pragma unroll
+  for (int i = 0; i < RT; ++i) aoff[i] = (i >> 1) * BLK + (((i & 1) << 5) ^ hx);
+#pragma unroll
+  for (int j = 0; j < CTW; ++j) {
+    const int ct = wave + 4 * j;                                             // < NCT: NCT is a multiple of 4
+    boff[j] = (YB + (ct >> 1)) * BLK + (((ct & 1) << 5) ^ hx);
+  }
+  auto read_frag = [&](unsigned addr, bf16x4& lo, bf16x4& hi) __attribute__((always_inline)) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:256" : "=&v"(lo), "=&v"(hi) : "v"(addr));
+  };
+  bf16x4 alo[2][RT], ahi[2][RT], blo[2][CTW], bhi[2][CTW];
+  auto read_kstep = [&](unsigned st, int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) read_frag(st + ks * 2048 + aoff[i], alo[ks][i], ahi[ks][i]);
+#pragma unroll
+    for (int j = 0; j < CTW; ++j) read_frag(st + ks * 2048 + boff[j], blo[ks][j], bhi[ks][j]);
+  };
+  auto wait_kstep = [&](int ks) __attribute__((always_inline)) {               // every read issued so far has returned; ties the fragments
+#pragma unroll                                                                // to the wait so that no MFMA is scheduled above it
+    for (int i = 0; i < RT; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[ks][i]), "+v"(ahi[ks][i]));
+#pragma unroll
+    for (int j = 0; j < CTW; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[ks][j]), "+v"(bhi[ks][j]));
+  };
+  auto mma_kstep = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < CTW; ++j) {
+      const bf16x8 bf = bf16x8{blo[ks][j][0], blo[ks][j][1], blo[ks][j][2], blo[ks][j][3], bhi[ks][j][0], bhi[ks][j][1], bhi[ks][j][2], bhi[ks][j][3]};
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const bf16x8 af = bf16x8{alo[ks][i][0], alo[ks][i][1], alo[ks][i][2], alo[ks][i][3], ahi[ks][i][0], ahi[ks][i][1], ahi[ks][i][2], ahi[ks][i][3]};
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  for (int kt = 0; kt < nk; ++kt) {
+    // tiles kt+1 .. min(kt+2, nk-1) may stay in flight; tile kt must have landed (vmcnt counts this wave's DMAs in issue order)
+    const int younger = min(NST - 2, nk - 1 - kt);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NDMA) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // every wave's pieces of tile kt are in LDS; stage (kt+3) % 4 (read in trip kt-1) is free
+    const unsigned st = rd0 + (kt & (NST - 1)) * STAGE;
+    read_kstep(st, 0);
+    if (kt + NST - 1 < nk) issue_tile(kt + NST - 1);      // address arithmetic of the next DMAs under the first reads' latency
+    wait_kstep(0);
+    read_kstep(st, 1);                              // in flight under the MFMAs of k-step 0
+    mma_kstep(0);
+    wait_kstep(1);
+    mma_kstep(1);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  dw += (size_t)(bz % (nrep & 0xffff)) * rep_stride;
+  flush_tile_rows<BMW, NCT, RT, CTW>(acc, reinterpret_cast<float*>(wr_all), dw, g, cd0, col0, ncols, wave, lane,
+                                     [&](int t) { return taptab[t] >> 16; }, (nrep >> 16) & 3);
+}
+
+template <int NCT>
+int launch_wgrad_ring(const void* dy, const void* src, float* dw, const ast_gather_t& g, int P, hipStream_t s) {
+  constexpr int LDS = 4 * (2 + NCT / 2) * 64 * 64 + 64;
+  static_assert(64 * NCT * 16 * 4 <= 4 * (2 + NCT / 2) * 64 * 64, "the flush tile overlays the ring");
+  static bool attr_set = false;
+  if (!attr_set) {
+    AST_HIP(hipFuncSetAttribute((const void*)wgrad_ring_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const int gx = (g.Cd + 63) / 64, gy = (g.ntaps * g.Cs + NCT * 16 - 1) / (NCT * 16);
+  const int tiles = gx * gy;
+  const char* wte = getenv("AST_WGRAD_WG_TARGET");
+  const int wg_target = wte ? atoi(wte) : (P >= 1500000 ? 768 : (NCT >= 12 ? 384 : 256));
+  int nsplit = std::max(1, std::min((P + 4 * 64 - 1) / (4 * 64), (wg_target + tiles - 1) / tiles));
+  if (g_wg_slab) nsplit = std::min(nsplit, g_wg_nrep);
+  int pps = (P + nsplit - 1) / nsplit;
+  pps = (pps + 63) / 64 * 64;
+  nsplit = (P + pps - 1) / pps;
+  const unsigned dy_bytes = (unsigned)((size_t)P * g.Cd * 2);
+  const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * 2);
+  const int total = gx * gy * nsplit;
+  g_wg_slices = nsplit;
+  hipLaunchKernelGGL((wgrad_ring_kernel<NCT>), dim3((total + 7) / 8 * 8), dim3(256), LDS, s, (const bf16_t*)dy, (const bf16_t*)src, dw, g, P, pps,
+                     dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm, gx, gy, nsplit, wg_nrep_arg(), g_wg_rep_stride);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T, int BMW, int NCT>
 int launch_wgrad(const void* dy, const void* src, float* dw, const ast_gather_t& g, int P, hipStream_t s) {
   // two pixel groups for the pixel-rich layers only: measured 172 800 pixels -11 % (51 -> 45 us), 43 200 pixels +20 %
@@ -970,6 +1164,12 @@ extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_g
   const char* te = getenv("AST_WGRAD_TAP");                  // read per call (host side only): tests toggle it at run time
   const bool tap_on = te && atoi(te) != 0;
   if (tap_on && !g_wg_slab && g.Cd >= 64) { AST_DISPATCH_T(dtype, { return launch_wgrad_tap<T>(dy, src, dw, g, P, s); }); }
+  const char* re = getenv("AST_WGRAD_RING");                 // read per call (host side only): tests toggle it at run time
+  if (dtype == AST_BF16 && bmw == 64 && !(re && atoi(re) == 0)) {
+    if (nct == 4) return launch_wgrad_ring<4>(dy, src, dw, g, P, s);
+    if (nct == 8) return launch_wgrad_ring<8>(dy, src, dw, g, P, s);
+    return launch_wgrad_ring<12>(dy, src, dw, g, P, s);
+  }
   WHaloPlan whp;
   const bool halo = plan_wgrad_halo(g, dtype, nct, bmw, whp);
 #define AST_WG(B_, N_) do { if (halo) return launch_wgrad_halo<T, B_, N_>(dy, src, dw, g, whp, s); \

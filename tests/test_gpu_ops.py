@@ -304,6 +304,54 @@ def test_wgrad_tap_kernel(dtype, cin, cout, k, stride, H, W, N):
             assert rel_err(dw, 2.0 * ref) < tol, (wgs, rel_err(dw, 2.0 * ref))
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,N", [
+    (64, 64, 3, 1, 30, 50, 4),       # 576 columns = three 192-column tiles
+    (32, 64, 3, 2, 37, 53, 3),       # 288 columns: the second column tile half empty; stride 2, odd sizes
+    (64, 96, 3, 1, 17, 16, 2),       # partial second row tile (96 output channels)
+    (128, 192, 3, 1, 9, 19, 3),
+    (512, 512, 3, 1, 5, 10, 2),      # deep layer: 100 pixels = two trips, the second one 36 pixels
+    (40, 64, 1, 2, 22, 31, 2),       # 1x1 shortcut, 40 columns: the 64-column tile (NCT = 4)
+    (8, 64, 3, 1, 12, 15, 1),        # 72 columns: the 128-column tile (NCT = 8), taps of ONE 16-byte chunk
+    (64, 64, 3, 1, 3, 5, 1),         # 15 pixels: one partial trip, fewer tiles than ring stages
+])
+def test_wgrad_ring_kernel(cin, cout, k, stride, H, W, N):
+    """The LDS-DMA ring weight-gradient kernel (bf16, more than 32 output channels) against a plain PyTorch fp32 reference of the same
+    contraction and against the register-staged kernel it replaces (AST_WGRAD_RING=0), with the default pixel slicing, with ONE
+    slice (the longest ring run: every stage reused many times, the tail trips with 2 / 1 / 0 younger tiles in flight) and with
+    as many slices as the pixels allow; a second launch into the same buffer must ADD."""
+    from ast_amd._lib import check, dcode, lib, ptr, stream
+    dtype = torch.bfloat16
+    config.set_compute_dtype(dtype)
+    torch.manual_seed(12)
+    pad = 1 if k == 3 else 0
+    g, (Ho, Wo) = ops.gather_direct(N, H, W, cin, cout, k, stride, pad)
+    x = torch.randn(N, H, W, cin, device=DEV).to(dtype)
+    dy = torch.randn(N, Ho, Wo, cout, device=DEV).to(dtype)
+    xr = x.float().permute(0, 3, 1, 2).contiguous()
+    w = torch.zeros(cout, cin, k, k, device=DEV, requires_grad=True)
+    F.conv2d(xr, w, stride=stride, padding=pad).backward(dy.float().permute(0, 3, 1, 2))
+    ref = w.grad.permute(0, 2, 3, 1).reshape(cout, k * k, cin)
+    tol = 2e-5                                               # f32 accumulation of the stored values: only the summation order differs
+
+    def run(into=None, **env):
+        with _env(**env):
+            dw = torch.zeros(cout, k * k, cin, device=DEV) if into is None else into.clone()
+            check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(dw), g, dcode(dtype), stream()), "ast_wgrad")
+            torch.cuda.synchronize()
+        return dw
+    old = run(AST_WGRAD_RING=0)
+    assert rel_err(old, ref) < tol
+    for target in (None, 1, 100000):
+        env = {"AST_WGRAD_RING": 1}
+        if target is not None:
+            env["AST_WGRAD_WG_TARGET"] = target
+        new = run(**env)
+        assert rel_err(new, ref) < tol, (target, rel_err(new, ref))
+        assert rel_err(new, old) < tol
+        twice = run(into=new, **env)
+        assert rel_err(twice, 2.0 * ref) < tol, (target, rel_err(twice, 2.0 * ref))
+
+
 @pytest.mark.parametrize("R_out,R_in", [(2, 8), (16, 32), (64, 128), (3, 300)])
 def test_rowmix_fwd_bwd(R_out, R_in):
     """ast_rowmix (class prototypes / prototype gather / section means, style_encoder.py:243-253, losses.py:88,142) for

@@ -26,9 +26,15 @@ for name in layers:
     wsz = torch.zeros(N * Ho * Wo * Cd, device="cuda")
     rep = int(os.environ.get("WGRAD_REP", "1"))                 # gradient replicas (ast_wgrad_rep)
     dy = torch.randn(N, Ho, Wo, Cd, device="cuda").to(dt); dw = torch.zeros(rep, Cd, k * k, Cs, device="cuda")
+    nsl = int(os.environ.get("WGRAD_SLABS", "0"))             # slab flush (ast_wgrad_slab): plain stores into one copy per pixel slice
+    if nsl:
+        import ctypes
+        slabs = torch.zeros(nsl, Cd, k * k, Cs, device="cuda"); sl_out = ctypes.c_int(0)
     def run():
         if wgrad:
-            if rep > 1:
+            if nsl:
+                check(lib().ast_wgrad_slab(ptr(dy), ptr(x), ptr(slabs), g, dcode(dt), nsl, ctypes.byref(sl_out), stream()))
+            elif rep > 1:
                 check(lib().ast_wgrad_rep(ptr(dy), ptr(x), ptr(dw), g, dcode(dt), rep, stream()))
             else:
                 check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(dw), g, dcode(dt), stream()))
