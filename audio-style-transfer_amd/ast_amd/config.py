@@ -51,4 +51,16 @@ fused_finalize = _os.environ.get("AST_FUSED_FINALIZE", "0") != "0"
 # Slab flush of the pixel-rich conv layers' weight gradients (ast_wgrad_slab + ast_slab_sum): every pixel slice of a launch stores
 # its partial dW into its own copy (plain stores) and one launch per model sums the copies at the end of the backward pass, instead
 # of f32 atomics into 8 replicas.  Value = copies kept per small weight (also the cap on a launch's pixel slices); 0 = replicas.
-wgrad_slabs = int(_os.environ.get("AST_WGRAD_SLABS", "128"))
+# Opt-in: isolated launches gain 2-5 us per layer (profiles/r03/wg_rows_layers.txt), the step does not -- 6.34 / 6.24 / 6.29 ms with
+# 128 slabs against 6.27 / 6.24 / 6.27 with replicas (ab_slabs_step.txt), 6.16 / 6.15 / 6.20 against 6.15 / 6.13 / 6.10 with the
+# deferred launches (ab_defer_flush.txt): the summing pass and the extra 19-25 MB of partial tiles per layer cost what the atomics did.
+wgrad_slabs = int(_os.environ.get("AST_WGRAD_SLABS", "0"))
+
+# Convolution weight gradients deferred to the bank's end-of-backward flush (they are leaves of the backward graph): the data-
+# gradient chain runs without them, and the banks' weight gradients run on the flush streams afterwards, longest first.
+# Same box, three runs each: 6.24 / 6.25 / 6.20 ms per step inline against 5.97 / 6.11 / 6.08 deferred (profiles/r03/ab_defer.txt).
+# On a side stream BESIDE the chain instead (AST_WGRAD_STREAM=1) the step takes 7.4-7.5 ms: a CU-filling kernel next to a chain of
+# short dependent kernels delays every one of them (profiles/r03/ab_wstream.txt).  More than one stream per bank for the deferred
+# launches loses as well (2: 6.01 / 6.21 / 6.13, 3: 6.35, 4: 6.43; profiles/r03/ab_defer_streams.txt).
+wgrad_defer = _os.environ.get("AST_WGRAD_DEFER", "1") != "0"
+wgrad_defer_streams = int(_os.environ.get("AST_WGRAD_DEFER_STREAMS", "1"))   # streams per bank that share its deferred launches

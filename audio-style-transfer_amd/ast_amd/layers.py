@@ -39,6 +39,8 @@ class WeightBank:
         self._pin_used = 0
         self._conv_dirty = False
         self._slab_recs = []          # (PackedWeight, pixel slices) of this backward pass's slab-mode weight gradients
+        self._conv_deferred = []      # config.wgrad_defer: (dy, src, dwp, geometry, replicas, PackedWeight) launched by _flush
+        self._defer_streams = []
         self.d_train = self.d_eval = None
         self._dev_consts = {}         # content -> device tensor (descriptor tables, tile lists): see _const_dev
         self._packed = {}             # (entry index, dtype, size) -> the entry's packed images and scratch
@@ -175,6 +177,9 @@ class WeightBank:
         self._lin_deferred.append((pw, dy, x))
         self.request_flush(conv=False)
 
+    def defer_conv_wgrad(self, dy, src, dwp, g, replicas, pw):
+        self._conv_deferred.append((dy, src, dwp, g, replicas, pw))
+
     def note_slab(self, pw, slices):
         if any(p is pw for p, _ in self._slab_recs):
             raise NotImplementedError("a convolution weight was used twice in one backward pass: its slab-mode gradient does not "
@@ -192,6 +197,34 @@ class WeightBank:
             slabs = (C.c_int32 * n)(*[sl for _, sl in part])
             check(lib().ast_slab_sum(bases, sizes, slabs, n, stream()), "ast_slab_sum")
 
+    def _launch_deferred(self, origin):
+        """The deferred convolution weight gradients of this backward pass (config.wgrad_defer), longest first, spread over
+        config.wgrad_defer_streams streams: the current (flush) stream and helpers forked from `origin` -- the stream the flush
+        was forked from -- that the flush stream then waits for (sibling waits; a stream never waits on its own child, streams.py)."""
+        items, self._conv_deferred = self._conv_deferred, []
+        cur = torch.cuda.current_stream()
+        k = max(1, min(config.wgrad_defer_streams, len(items)))
+        if k > 1 and cur != origin:
+            while len(self._defer_streams) < k - 1:
+                self._defer_streams.append(torch.cuda.Stream(device=self.d_tiles.device))
+            lanes = [cur] + self._defer_streams[:k - 1]
+            for st in lanes[1:]:
+                streams.fork(st, origin)
+        else:
+            lanes = [cur]
+        cost = lambda it: float(it[3].N) * it[3].Hm * it[3].Wm * max(it[3].Cd, 32) * max(it[3].ntaps * it[3].Cs, 64)
+        load = [0.0] * len(lanes)
+        for it in sorted(items, key=cost, reverse=True):
+            i = load.index(min(load))
+            load[i] += cost(it)
+            dy, src, dwp, g, replicas, pw = it
+            dy.record_stream(lanes[i])
+            src.record_stream(lanes[i])
+            with torch.cuda.stream(lanes[i]):
+                ops._wgrad_launch(dy, src, dwp, g, replicas, pw)
+        for st in lanes[1:]:
+            cur.wait_stream(st)
+
     def request_flush(self, conv=True):
         self._conv_dirty = self._conv_dirty or conv
         if not self._flush_pending:
@@ -200,12 +233,15 @@ class WeightBank:
 
     def _flush(self):
         self._flush_pending = False
+        if ops._WgradStream.stream is not None and ops._WgradStream.dirty:      # the weight-gradient launches of this backward pass
+            ops._WgradStream.dirty = False
+            streams.join(torch.cuda.current_stream(), ops._WgradStream.stream)
         if self._conv_dirty:
             self._conv_dirty = False
             from . import _lib as _L
             if _L.PROFILE_CALLS is not None:   # read the packed f32 staging + the master (spectral-norm term), add into the gradient
                 _L.NEXT_BYTES = sum((e.dwp.numel() * 4 if e.dwp is not None else 0) + 3 * e.Co * e.Ci * e.KK * 4 for e in self.entries if e.dwp is not None)
-            side = None
+            side, origin = None, torch.cuda.current_stream()
             if _ParallelFlush.active:
                 # the banks' flushes touch disjoint, persistent buffers (staging arena, masters, flat gradient): inside
                 # parallel_flush() each bank's pair of kernels runs on its own stream and the context joins them
@@ -215,6 +251,8 @@ class WeightBank:
                 streams.fork(side, torch.cuda.current_stream())
                 _ParallelFlush.pending.append(side)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                if self._conv_deferred:
+                    self._launch_deferred(origin)
                 if self._slab_recs:
                     self._sum_slabs()
                 check(lib().ast_weight_grads_flush_t(ptr(self.d_train), ptr(self.d_tiles), self.ntiles, stream()),

@@ -213,7 +213,31 @@ def _igemm(src, wgt, bias, dst, g, flags=0, stats=None, bn=None, per_image=False
         PROFILE.append((f"igemm_kernel<{dt},{_igemm_config(g, dcode(src.dtype))}>", fl, by, e0, e1))
 
 
+class _WgradStream:
+    """Weight gradients are leaves of the backward graph: with a stream set here (Trainer, AST_WGRAD_STREAM=1) the convolution
+    weight-gradient launches go to that stream -- it waits for the node's stream, nothing waits for it until the bank's flush --
+    so the data-gradient chain does not carry them."""
+    stream = None
+    dirty = False          # launches since the last join (one join per backward pass: redundant graph edges are not free, DESIGN 9.4)
+
+
 def _wgrad(dy, src, dwp, g, replicas=1, pw=None):
+    if pw is not None and config.wgrad_defer and PROFILE is None:
+        pw.bank.defer_conv_wgrad(dy, src, dwp, g, replicas, pw)       # launched by the bank's end-of-backward flush, on its stream
+        return
+    W = _WgradStream.stream
+    if W is not None and PROFILE is None:
+        _WgradStream.dirty = True
+        W.wait_stream(torch.cuda.current_stream())
+        dy.record_stream(W)
+        src.record_stream(W)
+        with torch.cuda.stream(W):
+            _wgrad_launch(dy, src, dwp, g, replicas, pw)
+        return
+    _wgrad_launch(dy, src, dwp, g, replicas, pw)
+
+
+def _wgrad_launch(dy, src, dwp, g, replicas=1, pw=None):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

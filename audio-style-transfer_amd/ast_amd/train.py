@@ -386,8 +386,15 @@ class Trainer:
         if self._matched and c.bucketed and self._dist and not self._simple:
             self._backward_bucketed(total, style_emb, content_emb)
         else:
-            with layers_mod.parallel_flush():     # the three generator banks' gradient flushes side by side
-                total.backward()
+            if os.environ.get("AST_WGRAD_STREAM", "0") != "0" and not self._matched:
+                if getattr(self, "_wstream", None) is None:
+                    self._wstream = torch.cuda.Stream(device=self.device)
+                ops._WgradStream.stream = self._wstream
+            try:
+                with layers_mod.parallel_flush():     # the three generator banks' gradient flushes side by side
+                    total.backward()
+            finally:
+                ops._WgradStream.stream = None
         parts["total"] = total.detach()
         return parts
 

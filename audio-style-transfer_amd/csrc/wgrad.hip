@@ -359,95 +359,100 @@ int launch_wgrad_pg(const void* dy, const void* src, float* dw, const ast_gather
 }
 
 // ---------------------------------------------------------------------------
-// wgrad_ring_kernel (bf16): the same contraction, operand staging and MFMA fragments as wgrad_kernel<bf16, 64, NCT, 1>, with the K
-// loop rebuilt around the one thing the round-3 probe blamed (tools/halo_probe.sh: launch time = trips x 1.6 us + slices x flush):
-// a 64-pixel trip of the register-staged loop costs ~3 600 cycles for 384 cycles of MFMA because the NEXT tile's loads are
-// issued only after this tile has been stored, so every trip waits out a full memory round trip with one workgroup on the CU.
-// Here the operands travel by LDS-DMA (buffer_load_dwordx4 ... lds: global memory -> LDS, no VGPRs, no ds_write) into a RING of
-// four stages: at trip t the tiles t+1, t+2 and (just issued) t+3 are in flight, the wave waits with a COUNTED s_waitcnt vmcnt
-// for tile t only, one raw s_barrier per trip makes every wave's pieces of tile t visible (and says that stage (t+3) % 4, read in
-// trip t-1, is free), then transposed reads + MFMAs.
-// LDS-DMA writes wave-uniform base + lane x 16 B, so the image is cut into PIECES of 16 pixel rows x 64 B that one wave-instruction
-// fills linearly: stage = [column block j][pixel row r][64 B], block j = columns 32j..32j+31 (bf16).  Wave w owns rows 16w..16w+15
-// of every block: a lane keeps ONE pixel row for the whole launch (one pixel decode per tile, as before).  A transposed read of a
-// half-wave touches rows {q, q+8} x 32 B of one block at a 64-byte pitch; the 32-byte half h of row r is stored at h ^ ((r >> 3) & 1)
-// -- applied on the SOURCE side (which chunk a lane fetches), the LDS side stays linear -- and the 32 lanes fall on 64 distinct banks.
+// wgrad_rows_kernel (bf16; 3x3 stride-1 "same" convolutions with Cs and Cd multiples of 64: conv2 of every ResBlock).
+// What bounds the gathered kernel above is the number of cache LINES its loads touch, not bytes or latency: a K trip of 64 pixels
+// x 192 columns fetches 64 x (128 B of dy + 3 taps x 128 B of source) as 16-byte chunks laid out 4 lanes to a 64-byte block --
+// 512 half-line touches per trip, ~4 cycles each in the CU's texture path = the 2 000 cycles a trip measures (0.86-1.1 us with
+// one or two workgroups on the CU, from L2 or from HBM alike, with register staging or with an LDS-DMA ring: profiles/r03/
+// wg_ring_layers.txt).  The three kw taps of a pixel are the SAME three source lines its neighbours read, so this kernel stages
+// source LINES, not gathered columns:
+//   workgroup = 64 output channels x (one kernel row kh, its three kw taps, 64 source channels) x a slice of the pixels;
+//   K trip = 64 consecutive pixels p0.. of the flattened (n, h, w) grid: 64 dy lines (128 B = 64 channels each) and the 66 source
+//   lines p0 + (kh-1) W - 1 ... + 64 -- in a stride-1 "same" convolution tap (kh, kw) of pixel p is line p + (kh-1) W + (kw-1) of
+//   the flattened source, across row and image ends too, where the convolution wants zeros instead: a 16-bit AND mask per
+//   (pixel, kw) -- h + kh - 1 and w + kw - 1 inside the image -- computed by one wave per trip, kept beside the tile and applied
+//   to the B fragments (8 consecutive pixels of one channel per lane = one ds_read_b128 of masks);
+//   130 full-line touches per trip instead of 512 halves, by LDS-DMA (8 lanes x 16 B = one line, 8 lines per wave-instruction)
+//   into a ring of four stages, one s_barrier per trip, counted s_waitcnt vmcnt (tiles t+1 .. t+3 in flight under tile t's MFMAs).
+// LDS images are [line][128 B]; the MFMA operands are read transposed (ds_read_b64_tr_b16) at a 128-byte pitch, so the 16-byte
+// chunk c of line r is kept at position c ^ row_swz(r) -- applied on the SOURCE side of the DMA, whose LDS side is lane-linear --
+// which spreads any 8 rows {a .. a+3, a+8 .. a+11} that a half-wave reads over all 64 banks.
+// All reads and writes of the ring are inline assembly with hand-placed waits: the compiler puts s_waitcnt vmcnt(0) in front of
+// every LDS access it can see while an LDS-DMA is in flight.
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int row_swz(int r) { return (((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1; }
 
-template <int NCT>
-__global__ __launch_bounds__(256) void wgrad_ring_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ src, float* __restrict__ dw,
-                                                         const ast_gather_t g, const int P, const int pps, const unsigned dy_bytes,
-                                                         const unsigned src_bytes, const float rcp_hw, const float rcp_w, const int gx,
-                                                         const int gy, const int gz, const int nrep, const long rep_stride) {
-  constexpr int BMW = 64, BKP = 64, E = 8, ES = 2;
-  constexpr int BNW = NCT * 16;
-  constexpr int YB = 2, XB = NCT / 2;               // 64-byte column blocks of the dy / source images
-  constexpr int BLK = BKP * 64;                     // bytes of one block: 64 pixel rows x 64 B
-  constexpr int STAGE = (YB + XB) * BLK;
-  constexpr int NST = 4;
-  constexpr int NDMA = YB + XB;                     // LDS-DMA instructions per wave and tile
-  constexpr int RT = BMW / 16, CTW = (NCT + 3) / 4;
+__global__ __launch_bounds__(256, 2) void wgrad_rows_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ src, float* __restrict__ dw,
+                                                            const ast_gather_t g, const int P, const int pps, const unsigned dy_bytes,
+                                                            const unsigned src_bytes, const float rcp_hw, const float rcp_w, const int gx,
+                                                            const int gy, const int gz, const int nrep, const long rep_stride) {
+  constexpr int NST = 4, RT = 4, CTW = 3;
+  constexpr int DYB = 64 * 128, XB = 72 * 128, MB = 3 * 64 * 2;      // dy lines, source lines (66 used), masks [kw][pixel] u16
+  constexpr int STAGE = DYB + XB + MB;
   constexpr unsigned OOB = 0x80000000u;
-  static_assert(NCT % 4 == 0 && NDMA * 3 <= 63 && BKP == 64, "tile");
-  extern __shared__ __attribute__((aligned(16))) unsigned char wr_all[];
-  int* taptab = reinterpret_cast<int*>(wr_all + NST * STAGE);
+  extern __shared__ __attribute__((aligned(16))) unsigned char wq_all[];
+  int* taptab = reinterpret_cast<int*>(wq_all + NST * STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int chunk = gridDim.x >> 3;                 // XCD-aware order, as wgrad_kernel
+  const int chunk = gridDim.x >> 3;                 // XCD-aware order: the workgroups that share a dy slice sit on one XCD
   const int tix = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tix >= gx * gy * gz) return;
   const int bx = tix / (gz * gy), bz = (tix / gy) % gz, by = tix % gy;
-  const int cd0 = bx * BMW, col0 = by * BNW;
-  const int ncols = g.ntaps * g.Cs;
-  const int HWm = g.Hm * g.Wm;
+  const int kh = by % 3, cs0 = (by / 3) * 64, cd0 = bx * 64;
+  const int W = g.Wm, H = g.Hm;
+  WG_STAMP(0); WG_STAMP(7);
   const int p_begin = bz * pps, p_end = min(P, p_begin + pps);
   const __amdgpu_buffer_rsrc_t dyR = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t srcR = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, src_bytes, 0x00020000);
 #pragma unroll
   for (int t = 0; t < AST_MAX_TAPS; ++t)
     if (tid == t) taptab[t] = g.tap[t];
-  __syncthreads();
+  __syncthreads();                                  // (before any DMA is in flight)
+  const int wt0 = taptab[kh * 3] >> 16, wt1 = taptab[kh * 3 + 1] >> 16, wt2 = taptab[kh * 3 + 2] >> 16;
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)wq_all;
 
-  // loader role: pixel row lrow of the tile, 16-byte chunk q of every 64-byte block; the chunk FETCHED for LDS position q is the
-  // one whose 32-byte half is h ^ ((lrow >> 3) & 1)
-  const int lrow = tid >> 2, q = tid & 3;
-  const int dq = ((((q >> 1) ^ ((lrow >> 3) & 1)) & 1) << 1) | (q & 1);       // data chunk inside the block
-  int ycd[YB];                                      // channel of the lane's dy chunk per block (>= Cd: no such channel)
+  // loader role: wave w fills lines 16w .. 16w+15 of both images (two wave-instructions of 8 lines each); wave 0 also the two halo
+  // lines 64, 65 of the source.  Lane = (line lr of the instruction, chunk position cp); it FETCHES chunk cp ^ row_swz(line).
+  const int lr = lane >> 3, cp = lane & 7;
+  int dyp[2], xgl[3];                               // pixel of the lane's dy line / flattened source line, at trip 0
+  unsigned dyo[2], xo[3];                           // their byte offsets
 #pragma unroll
-  for (int j = 0; j < YB; ++j) ycd[j] = cd0 + (4 * j + dq) * E;
-  int xdelta[XB], xdh[XB], xdw[XB];                 // per source block: byte delta of (tap, channel), tap offsets; dh = 1 << 20: no column
-#pragma unroll
-  for (int j = 0; j < XB; ++j) {
-    const int col = col0 + (4 * j + dq) * E;
-    xdelta[j] = 0; xdh[j] = 1 << 20; xdw[j] = 0;
-    if (col < ncols) {
-      const int t = col / g.Cs, c = col - t * g.Cs;
-      int dh, dw_, wt;
-      decode_tap(taptab[t], dh, dw_, wt);
-      xdh[j] = dh; xdw[j] = dw_;
-      xdelta[j] = ((dh * g.Ws + dw_) * g.Cs + c) * ES;
+  for (int a = 0; a < 3; ++a) {
+    const int line = a < 2 ? 16 * wave + 8 * a + lr : 64 + lr;
+    const int c = cp ^ row_swz(line);
+    if (a < 2) {
+      dyp[a] = p_begin + line;
+      dyo[a] = (unsigned)((dyp[a] * g.Cd + cd0) * 2 + c * 16);
     }
+    xgl[a] = p_begin + (kh - 1) * W - 1 + line;
+    xo[a] = (unsigned)((xgl[a] * g.Cs + cs0) * 2 + c * 16);
   }
   auto issue_tile = [&](int kt) __attribute__((always_inline)) {
-    unsigned char* st = wr_all + (kt & (NST - 1)) * STAGE + wave * 1024;      // this wave's 16 rows of block 0 (wave-uniform)
-    const int p = p_begin + kt * BKP + lrow;
-    const bool pv = p < p_end;
-    const int pp = pv ? p : 0;
+    unsigned char* st = wq_all + (kt & (NST - 1)) * STAGE;
+    const int adv = kt * 64;
 #pragma unroll
-    for (int j = 0; j < YB; ++j) {
-      const bool ok = pv && ycd[j] < g.Cd;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(dyR, (lds_void_t*)(st + j * BLK), 16, ok ? (unsigned)((pp * g.Cd + ycd[j]) * ES) : OOB, 0, 0, 0);
-    }
-    const int n = fdiv(pp, HWm, rcp_hw), rem = pp - n * HWm;
-    const int hm = fdiv(rem, g.Wm, rcp_w), wq = rem - hm * g.Wm;
-    const int hs0 = pv ? hm * g.sh + g.oh : -(1 << 21), ws0 = wq * g.sw + g.ow;
-    const int base = (((n * g.Hs + hs0) * g.Ws + ws0) * g.Cs) * ES;
+    for (int a = 0; a < 2; ++a)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dyR, (lds_void_t*)(st + (2 * wave + a) * 1024), 16,
+                                               dyp[a] + adv < p_end ? dyo[a] + (unsigned)(adv * g.Cd * 2) : OOB, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < XB; ++j) {
-      const bool ok = (unsigned)(hs0 + xdh[j]) < (unsigned)g.Hs && (unsigned)(ws0 + xdw[j]) < (unsigned)g.Ws;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcR, (lds_void_t*)(st + (YB + j) * BLK), 16, ok ? (unsigned)(base + xdelta[j]) : OOB, 0, 0, 0);
+    for (int a = 0; a < 2; ++a)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcR, (lds_void_t*)(st + DYB + (2 * wave + a) * 1024), 16,
+                                               (unsigned)(xgl[a] + adv) < (unsigned)P ? xo[a] + (unsigned)(adv * g.Cs * 2) : OOB, 0, 0, 0);
+    if (wave == 0)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcR, (lds_void_t*)(st + DYB + 8 * 1024), 16,
+                                               (lr < 2 && (unsigned)(xgl[2] + adv) < (unsigned)P) ? xo[2] + (unsigned)(adv * g.Cs * 2) : OOB, 0, 0, 0);
+    if (wave == 1) {                                // the tile's masks: lane = pixel
+      const int p = p_begin + adv + lane;
+      const int n = fdiv(p, H * W, rcp_hw), rem = p - n * H * W;
+      const int h = fdiv(rem, W, rcp_w), w = rem - h * W;
+      const bool hv = kh == 0 ? h >= 1 : (kh == 2 ? h <= H - 2 : true);
+      const unsigned m0 = hv && w >= 1 ? 0xffffu : 0u, m1 = hv ? 0xffffu : 0u, m2 = hv && w <= W - 2 ? 0xffffu : 0u;
+      const unsigned ma = lds0 + (kt & (NST - 1)) * STAGE + DYB + XB + lane * 2;
+      asm volatile("ds_write_b16 %0, %1\n\tds_write_b16 %0, %2 offset:128\n\tds_write_b16 %0, %3 offset:256" :: "v"(ma), "v"(m0), "v"(m1), "v"(m2) : "memory");
     }
   };
 
@@ -457,44 +462,50 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(const bf16_t* __restric
 #pragma unroll
     for (int j = 0; j < CTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int li = lane & 15, gq = lane >> 4;
-  const int nk = (p_end - p_begin + BKP - 1) / BKP;
-  for (int t = 0; t < NST - 1; ++t)
-    if (t < nk) issue_tile(t);
-  // The transposed reads are INLINE ASSEMBLY with hand-placed s_waitcnt lgkmcnt: the compiler treats every LDS-DMA in flight as a
-  // possible writer of whatever a ds_read it can see reads and puts s_waitcnt vmcnt(0) in front of it -- which would wait for the
-  // tile issued a moment ago and serialise the ring.  (Stage separation is by ring index, which no alias analysis sees.)
-  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)wr_all;
-  const unsigned rd0 = lds0 + (8 * gq + (li >> 2)) * 64 + (li & 3) * 8;      // row r_lo of k-step 0, chunk of this lane, half 0
-  const unsigned hx = (gq & 1) << 5;                                         // rows r_lo and r_lo + 4 share bit 3 (= gq & 1)
-  unsigned aoff[RT], boff[CTW];                                              // byte offsets of the lane's A / B fragments inside a stage
+  // consumer role: wave w owns the 16 source channels 16w .. 16w+15 of each of the three kw taps (column tile j = kw) and all four
+  // 16-row tiles of the output channels.  Lane (li, gq): rows 8 gq + (li >> 2) (+ 4) of a 32-pixel k-step, 8 bytes (li & 3) of the tile.
+  const int li = lane & 15, gq = lane >> 4, q4 = li >> 2;
+  const int sub = (li & 1) * 8, ch = (li & 3) >> 1;
+  unsigned aoff[RT], boff[CTW][2];                  // byte offsets inside a stage (k-step 0; k-step 1 = + 32 lines = + 4096)
 #pragma unroll
-  for (int i = 0; i < RT; ++i) aoff[i] = (i >> 1) * BLK + (((i & 1) << 5) ^ hx);
-#pragma unroll
-  for (int j = 0; j < CTW; ++j) {
-    const int ct = wave + 4 * j;                                             // < NCT: NCT is a multiple of 4
-    boff[j] = (YB + (ct >> 1)) * BLK + (((ct & 1) << 5) ^ hx);
+  for (int i = 0; i < RT; ++i) {
+    const int r = 8 * gq + q4;                      // row_swz(r) == row_swz(r + 4) == row_swz(r + 32)
+    aoff[i] = r * 128 + (((2 * i + ch) ^ row_swz(r)) << 4) + sub;
   }
-  auto read_frag = [&](unsigned addr, bf16x4& lo, bf16x4& hi) __attribute__((always_inline)) {
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:256" : "=&v"(lo), "=&v"(hi) : "v"(addr));
-  };
+#pragma unroll
+  for (int j = 0; j < CTW; ++j)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int r = 8 * gq + q4 + j + 4 * hh;       // source line of pixel row (8 gq + q4 + 4 hh), tap kw = j
+      boff[j][hh] = DYB + r * 128 + (((2 * wave + ch) ^ row_swz(r)) << 4) + sub;
+    }
+  const unsigned moff = DYB + XB + 16 * gq;         // masks of the lane's 8 pixels: [kw][32 ks + 8 gq ..] u16
+
   bf16x4 alo[2][RT], ahi[2][RT], blo[2][CTW], bhi[2][CTW];
+  u32x4v mk[2][CTW];
   auto read_kstep = [&](unsigned st, int ks) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < RT; ++i) read_frag(st + ks * 2048 + aoff[i], alo[ks][i], ahi[ks][i]);
+    for (int i = 0; i < RT; ++i)
+      asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512" : "=&v"(alo[ks][i]), "=&v"(ahi[ks][i]) : "v"(st + ks * 4096 + aoff[i]));
 #pragma unroll
-    for (int j = 0; j < CTW; ++j) read_frag(st + ks * 2048 + boff[j], blo[ks][j], bhi[ks][j]);
+    for (int j = 0; j < CTW; ++j) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[ks][j]) : "v"(st + ks * 4096 + boff[j][0]));
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bhi[ks][j]) : "v"(st + ks * 4096 + boff[j][1]));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(mk[ks][j]) : "v"(st + moff + ks * 64 + j * 128));
+    }
   };
-  auto wait_kstep = [&](int ks) __attribute__((always_inline)) {               // every read issued so far has returned; ties the fragments
-#pragma unroll                                                                // to the wait so that no MFMA is scheduled above it
+  auto wait_kstep = [&](int ks) __attribute__((always_inline)) {               // every LDS read issued so far has returned; ties the
+#pragma unroll                                                                // fragments to the wait so that no use is scheduled above it
     for (int i = 0; i < RT; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[ks][i]), "+v"(ahi[ks][i]));
 #pragma unroll
-    for (int j = 0; j < CTW; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[ks][j]), "+v"(bhi[ks][j]));
+    for (int j = 0; j < CTW; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[ks][j]), "+v"(bhi[ks][j]), "+v"(mk[ks][j]));
   };
   auto mma_kstep = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < CTW; ++j) {
-      const bf16x8 bf = bf16x8{blo[ks][j][0], blo[ks][j][1], blo[ks][j][2], blo[ks][j][3], bhi[ks][j][0], bhi[ks][j][1], bhi[ks][j][2], bhi[ks][j][3]};
+      const u32x2v lo = __builtin_bit_cast(u32x2v, blo[ks][j]) & u32x2v{mk[ks][j][0], mk[ks][j][1]};
+      const u32x2v hi = __builtin_bit_cast(u32x2v, bhi[ks][j]) & u32x2v{mk[ks][j][2], mk[ks][j][3]};
+      const bf16x8 bf = __builtin_bit_cast(bf16x8, u32x4v{lo[0], lo[1], hi[0], hi[1]});
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
         const bf16x8 af = bf16x8{alo[ks][i][0], alo[ks][i][1], alo[ks][i][2], alo[ks][i][3], ahi[ks][i][0], ahi[ks][i][1], ahi[ks][i][2], ahi[ks][i][3]};
@@ -502,51 +513,124 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(const bf16_t* __restric
       }
     }
   };
+
+  const int nk = (p_end - p_begin + 63) / 64;
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nk) issue_tile(t);
+  WG_STAMP(1);
+#ifdef AST_STAMPS
+  long long ph[5] = {0, 0, 0, 0, 0};              // cycles of thread 0 in: wait for the tile's DMAs, barrier, reads of k-step 0 + DMA issue, reads 1 + MFMAs 0, MFMAs 1
+  long long tph = __builtin_readcyclecounter();
+#endif
   for (int kt = 0; kt < nk; ++kt) {
-    // tiles kt+1 .. min(kt+2, nk-1) may stay in flight; tile kt must have landed (vmcnt counts this wave's DMAs in issue order)
+    // tiles kt+1 .. min(kt+2, nk-1) may stay in flight; this wave's DMAs of tile kt must have landed (vmcnt counts them in issue
+    // order: 5 per tile on wave 0, 4 on the others) and its mask writes too
     const int younger = min(NST - 2, nk - 1 - kt);
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NDMA) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == 0) {
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    WG_PH(0);
     __builtin_amdgcn_s_barrier();                   // every wave's pieces of tile kt are in LDS; stage (kt+3) % 4 (read in trip kt-1) is free
-    const unsigned st = rd0 + (kt & (NST - 1)) * STAGE;
+    asm volatile("" ::: "memory");
+    WG_PH(1);
+    const unsigned st = lds0 + (kt & (NST - 1)) * STAGE;
     read_kstep(st, 0);
-    if (kt + NST - 1 < nk) issue_tile(kt + NST - 1);      // address arithmetic of the next DMAs under the first reads' latency
+    if (kt + NST - 1 < nk) issue_tile(kt + NST - 1);
     wait_kstep(0);
+    WG_PH(2);
     read_kstep(st, 1);                              // in flight under the MFMAs of k-step 0
     mma_kstep(0);
     wait_kstep(1);
+    WG_PH(3);
     mma_kstep(1);
+    WG_PH(4);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef AST_STAMPS
+  if (threadIdx.x == 0 && tix < 4096) { ast_wg_stamps[tix * 8 + 5] = (unsigned long long)((ph[0] << 32) | (ph[1] & 0xffffffffll)); ast_wg_phase[tix * 4 + 0] = ph[2]; ast_wg_phase[tix * 4 + 1] = ph[3]; ast_wg_phase[tix * 4 + 2] = ph[4]; ast_wg_phase[tix * 4 + 3] = nk; }
+#endif
+  WG_STAMP(2); WG_STAMP(3);
+
+  // flush: column tile j of wave w = tap (kh, kw = j), source channels cs0 + 16 w + li; rows = output channels cd0 + 16 i + 4 gq + r
   dw += (size_t)(bz % (nrep & 0xffff)) * rep_stride;
-  flush_tile_rows<BMW, NCT, RT, CTW>(acc, reinterpret_cast<float*>(wr_all), dw, g, cd0, col0, ncols, wave, lane,
-                                     [&](int t) { return taptab[t] >> 16; }, (nrep >> 16) & 3);
+  const int mode = (nrep >> 16) & 3;
+  const int wts[3] = {wt0, wt1, wt2};
+  if (mode == 0) {
+#pragma unroll
+    for (int j = 0; j < CTW; ++j)
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          unsafeAtomicAdd(dw + ((size_t)(cd0 + i * 16 + gq * 4 + r) * g.wtaps + wts[j]) * g.Cs + cs0 + wave * 16 + li, acc[i][j][r]);
+#ifdef AST_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    WG_STAMP(4); WG_STAMP(6);
+    return;
+  }
+  float* tile = reinterpret_cast<float*>(wq_all);   // [64 output channels][3 kw x 64 source channels]
+  __syncthreads();                                  // every wave has finished reading the ring
+#pragma unroll
+  for (int j = 0; j < CTW; ++j)
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[(i * 16 + gq * 4 + r) * 192 + j * 64 + wave * 16 + li] = acc[i][j][r];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CTW; ++j) {
+    float* dcol = dw + (size_t)wts[j] * g.Cs + cs0 + lane;         // 64 lanes = 256 contiguous bytes of one output channel's tap row
+    for (int row = wave; row < 64; row += 4) {
+      float* d = dcol + (size_t)(cd0 + row) * g.wtaps * g.Cs;
+      const float v = tile[row * 192 + j * 64 + lane];
+      if (mode == 2) *d = v; else unsafeAtomicAdd(d, v);
+    }
+  }
+#ifdef AST_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  WG_STAMP(4); WG_STAMP(6);
 }
 
-template <int NCT>
-int launch_wgrad_ring(const void* dy, const void* src, float* dw, const ast_gather_t& g, int P, hipStream_t s) {
-  constexpr int LDS = 4 * (2 + NCT / 2) * 64 * 64 + 64;
-  static_assert(64 * NCT * 16 * 4 <= 4 * (2 + NCT / 2) * 64 * 64, "the flush tile overlays the ring");
+// 3x3, stride 1, "same" size, taps in (kh, kw) order at offsets kh - 1, kw - 1, 64-channel multiples on both sides
+bool wgrad_rows_eligible(const ast_gather_t& g, int dtype) {
+  if (dtype != AST_BF16 || g.ntaps != 9 || g.sh != 1 || g.sw != 1 || g.Hm != g.Hs || g.Wm != g.Ws || (g.Cs & 63) || (g.Cd & 63)) return false;
+  for (int t = 0; t < 9; ++t) {
+    const int dh = (g.tap[t] & 255) - 64 + g.oh, dw = ((g.tap[t] >> 8) & 255) - 64 + g.ow;
+    if (dh != t / 3 - 1 || dw != t % 3 - 1) return false;
+  }
+  return true;
+}
+
+int launch_wgrad_rows(const void* dy, const void* src, float* dw, const ast_gather_t& g, int P, hipStream_t s) {
+  constexpr int LDS = 4 * (64 * 128 + 72 * 128 + 384) + 64;
+  static_assert(64 * 192 * 4 <= 4 * (64 * 128 + 72 * 128 + 384), "the flush tile overlays the ring");
   static bool attr_set = false;
   if (!attr_set) {
-    AST_HIP(hipFuncSetAttribute((const void*)wgrad_ring_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    AST_HIP(hipFuncSetAttribute((const void*)wgrad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  const int gx = (g.Cd + 63) / 64, gy = (g.ntaps * g.Cs + NCT * 16 - 1) / (NCT * 16);
+  const int gx = g.Cd / 64, gy = 3 * (g.Cs / 64);
   const int tiles = gx * gy;
   const char* wte = getenv("AST_WGRAD_WG_TARGET");
-  const int wg_target = wte ? atoi(wte) : (P >= 1500000 ? 768 : (NCT >= 12 ? 384 : 256));
+  const int wg_target = wte ? atoi(wte) : 384;          // 1.5 workgroups per CU (71 KB of LDS each); 256 and 512 measured slower (profiles/r03/wg_rows_layers.txt)
   int nsplit = std::max(1, std::min((P + 4 * 64 - 1) / (4 * 64), (wg_target + tiles - 1) / tiles));
   if (g_wg_slab) nsplit = std::min(nsplit, g_wg_nrep);
   int pps = (P + nsplit - 1) / nsplit;
   pps = (pps + 63) / 64 * 64;
   nsplit = (P + pps - 1) / pps;
   const unsigned dy_bytes = (unsigned)((size_t)P * g.Cd * 2);
-  const unsigned src_bytes = (unsigned)((size_t)g.N * g.Hs * g.Ws * g.Cs * 2);
+  const unsigned src_bytes = (unsigned)((size_t)P * g.Cs * 2);
   const int total = gx * gy * nsplit;
   g_wg_slices = nsplit;
-  hipLaunchKernelGGL((wgrad_ring_kernel<NCT>), dim3((total + 7) / 8 * 8), dim3(256), LDS, s, (const bf16_t*)dy, (const bf16_t*)src, dw, g, P, pps,
+  hipLaunchKernelGGL(wgrad_rows_kernel, dim3((total + 7) / 8 * 8), dim3(256), LDS, s, (const bf16_t*)dy, (const bf16_t*)src, dw, g, P, pps,
                      dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm, gx, gy, nsplit, wg_nrep_arg(), g_wg_rep_stride);
   AST_CHECK_LAUNCH();
   return 0;
@@ -1164,11 +1248,10 @@ extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_g
   const char* te = getenv("AST_WGRAD_TAP");                  // read per call (host side only): tests toggle it at run time
   const bool tap_on = te && atoi(te) != 0;
   if (tap_on && !g_wg_slab && g.Cd >= 64) { AST_DISPATCH_T(dtype, { return launch_wgrad_tap<T>(dy, src, dw, g, P, s); }); }
-  const char* re = getenv("AST_WGRAD_RING");                 // read per call (host side only): tests toggle it at run time
-  if (dtype == AST_BF16 && bmw == 64 && !(re && atoi(re) == 0)) {
-    if (nct == 4) return launch_wgrad_ring<4>(dy, src, dw, g, P, s);
-    if (nct == 8) return launch_wgrad_ring<8>(dy, src, dw, g, P, s);
-    return launch_wgrad_ring<12>(dy, src, dw, g, P, s);
+  const char* re = getenv("AST_WGRAD_ROWS");                 // read per call (host side only): tests toggle it at run time
+  if (!(re && atoi(re) == 0) && wgrad_rows_eligible(g, dtype)) {
+    if ((long)P * g.Cs * 2 >= (1L << 31)) AST_FAIL("ast_wgrad: source exceeds the 2 GiB buffer-addressing range");
+    return launch_wgrad_rows(dy, src, dw, g, P, s);
   }
   WHaloPlan whp;
   const bool halo = plan_wgrad_halo(g, dtype, nct, bmw, whp);

@@ -229,7 +229,7 @@ def test_wgrad_replicas_sum_to_the_gradient(dtype, cin, cout, k, stride, H, W, N
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout,k,stride,H,W,N", [(32, 32, 3, 1, 40, 61, 4), (8, 32, 3, 2, 64, 97, 4), (64, 64, 3, 1, 30, 50, 4), (32, 64, 1, 2, 40, 60, 2),
-                                                     (64, 128, 3, 2, 36, 75, 3), (2, 16, 3, 1, 57, 83, 2)])
+                                                     (64, 128, 3, 2, 36, 75, 3), (2, 16, 3, 1, 57, 83, 2), (128, 128, 3, 1, 9, 19, 3)])
 def test_wgrad_slab_store_and_sum(dtype, cin, cout, k, stride, H, W, N):
     """ast_wgrad_slab: every pixel slice STORES its partial gradient into its own copy of dW (no atomics); ast_slab_sum adds the
     copies into copy 0.  The copies start as NaN: a slice that left any element of its copy unwritten would poison the sum."""
@@ -304,32 +304,35 @@ def test_wgrad_tap_kernel(dtype, cin, cout, k, stride, H, W, N):
             assert rel_err(dw, 2.0 * ref) < tol, (wgs, rel_err(dw, 2.0 * ref))
 
 
-@pytest.mark.parametrize("cin,cout,k,stride,H,W,N", [
-    (64, 64, 3, 1, 30, 50, 4),       # 576 columns = three 192-column tiles
-    (32, 64, 3, 2, 37, 53, 3),       # 288 columns: the second column tile half empty; stride 2, odd sizes
-    (64, 96, 3, 1, 17, 16, 2),       # partial second row tile (96 output channels)
-    (128, 192, 3, 1, 9, 19, 3),
-    (512, 512, 3, 1, 5, 10, 2),      # deep layer: 100 pixels = two trips, the second one 36 pixels
-    (40, 64, 1, 2, 22, 31, 2),       # 1x1 shortcut, 40 columns: the 64-column tile (NCT = 4)
-    (8, 64, 3, 1, 12, 15, 1),        # 72 columns: the 128-column tile (NCT = 8), taps of ONE 16-byte chunk
-    (64, 64, 3, 1, 3, 5, 1),         # 15 pixels: one partial trip, fewer tiles than ring stages
+@pytest.mark.parametrize("cin,cout,H,W,N", [
+    (64, 64, 30, 50, 4),         # the 64-channel layer: three kernel-row workgroups per pixel slice
+    (64, 128, 17, 16, 2),        # two output-channel tiles
+    (128, 64, 9, 19, 3),         # two source-channel chunks; rows shorter than a 64-pixel trip (a trip spans 4 image rows)
+    (128, 192, 9, 19, 3),
+    (512, 512, 5, 10, 2),        # deep layer: 100 pixels = two trips, the second one 36 pixels
+    (64, 64, 3, 5, 1),           # 15 pixels: one partial trip, fewer tiles than ring stages
+    (64, 64, 1, 1, 7),           # 1 x 1 images: every tap but the centre one is padding
+    (64, 64, 40, 1, 2),          # one-pixel rows: w = 0 is the first AND the last column
+    (64, 64, 2, 150, 3),         # rows longer than a trip
+    (256, 64, 36, 75, 2),        # 12 workgroups share a dy slice
 ])
-def test_wgrad_ring_kernel(cin, cout, k, stride, H, W, N):
-    """The LDS-DMA ring weight-gradient kernel (bf16, more than 32 output channels) against a plain PyTorch fp32 reference of the same
-    contraction and against the register-staged kernel it replaces (AST_WGRAD_RING=0), with the default pixel slicing, with ONE
-    slice (the longest ring run: every stage reused many times, the tail trips with 2 / 1 / 0 younger tiles in flight) and with
-    as many slices as the pixels allow; a second launch into the same buffer must ADD."""
+def test_wgrad_rows_kernel(cin, cout, H, W, N):
+    """The line-staged weight-gradient kernel of the 3x3 stride-1 layers (bf16, channel counts multiples of 64: LDS-DMA ring, border
+    masks instead of gathered zeros) against a plain PyTorch fp32 reference of the same contraction and against the gathered kernel it
+    replaces (AST_WGRAD_ROWS=0), with the default pixel slicing, with ONE slice (the longest ring run: every stage reused, the tail
+    trips with 2 / 1 / 0 younger tiles in flight) and with as many slices as the pixels allow; a second launch into the same buffer
+    must ADD."""
     from ast_amd._lib import check, dcode, lib, ptr, stream
     dtype = torch.bfloat16
     config.set_compute_dtype(dtype)
     torch.manual_seed(12)
-    pad = 1 if k == 3 else 0
-    g, (Ho, Wo) = ops.gather_direct(N, H, W, cin, cout, k, stride, pad)
+    k = 3
+    g, (Ho, Wo) = ops.gather_direct(N, H, W, cin, cout, k, 1, 1)
     x = torch.randn(N, H, W, cin, device=DEV).to(dtype)
     dy = torch.randn(N, Ho, Wo, cout, device=DEV).to(dtype)
     xr = x.float().permute(0, 3, 1, 2).contiguous()
     w = torch.zeros(cout, cin, k, k, device=DEV, requires_grad=True)
-    F.conv2d(xr, w, stride=stride, padding=pad).backward(dy.float().permute(0, 3, 1, 2))
+    F.conv2d(xr, w, stride=1, padding=1).backward(dy.float().permute(0, 3, 1, 2))
     ref = w.grad.permute(0, 2, 3, 1).reshape(cout, k * k, cin)
     tol = 2e-5                                               # f32 accumulation of the stored values: only the summation order differs
 
@@ -339,10 +342,10 @@ def test_wgrad_ring_kernel(cin, cout, k, stride, H, W, N):
             check(lib().ast_wgrad(ptr(dy), ptr(x), ptr(dw), g, dcode(dtype), stream()), "ast_wgrad")
             torch.cuda.synchronize()
         return dw
-    old = run(AST_WGRAD_RING=0)
+    old = run(AST_WGRAD_ROWS=0)
     assert rel_err(old, ref) < tol
     for target in (None, 1, 100000):
-        env = {"AST_WGRAD_RING": 1}
+        env = {"AST_WGRAD_ROWS": 1}
         if target is not None:
             env["AST_WGRAD_WG_TARGET"] = target
         new = run(**env)

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "audio-style-transfer_amd")); sys.path.ins
 import numpy as np, torch
 from ast_amd import ops
 from ast_amd._lib import lib, check, ptr, stream, dcode
-SH = {"b3c2": (16, 18, 38, 256, 256, 3, 1), "b2c2": (16, 36, 75, 128, 128, 3, 1), "b1c2": (16, 72, 150, 64, 64, 3, 1)}
+SH = {"b4c2": (16, 9, 19, 512, 512, 3, 1), "b3c2": (16, 18, 38, 256, 256, 3, 1), "b2c2": (16, 36, 75, 128, 128, 3, 1), "b1c2": (16, 72, 150, 64, 64, 3, 1)}
 name = sys.argv[1] if len(sys.argv) > 1 else "b1c2"
 N, H, W, Cs, Cd, k, st = SH[name]
 dt = torch.bfloat16
@@ -34,7 +34,10 @@ assert f2(ph, n) == 0
 pa = np.frombuffer(ph, dtype=np.int64).reshape(n, 4)[:len(a)]
 trips = np.maximum(pa[:, 3], 1)
 sub = np.stack([a[:, 5] >> 32, a[:, 5] & 0xffffffff, pa[:, 0], pa[:, 1], pa[:, 2]], axis=1) / trips[:, None]
-print(f"  K loop per trip ({int(np.median(trips))} trips, thread 0 of pixel group 0): " + ", ".join(f"{nm} {np.median(sub[:, i]):.0f}" for i, nm in enumerate(["LDS store + wait for the loads", "barrier", "issue next loads", "LDS reads + MFMA", "barrier"])) + " cycles")
+rows = os.environ.get("AST_WGRAD_ROWS", "1") != "0" and Cs % 64 == 0 and Cd % 64 == 0 and st == 1      # the line-staged kernel's sub-phases
+names = (["wait for the tile's DMAs", "barrier", "reads of k-step 0 (returned) + DMA issue", "reads of k-step 1 (returned) + MFMAs 0 issued", "MFMAs 1 issued"] if rows else
+         ["LDS store + wait for the loads", "barrier", "issue next loads", "LDS reads + MFMA", "barrier"])
+print(f"  K loop per trip ({int(np.median(trips))} trips, thread 0): " + ", ".join(f"{nm} {np.median(sub[:, i]):.0f}" for i, nm in enumerate(names)) + " cycles")
 life = a[:, 4] - a[:, 0]
 us = (a[:, 6] - a[:, 7]) / 100.0
 print(f"  workgroup lifetime median {np.median(life):.0f} cycles = {np.median(us):.2f} us (shader clock {np.median(life / us) / 1e3:.2f} GHz); last workgroup ends at {(a[:, 6].max() - a[:, 7].min()) / 100.0:.1f} us")
