@@ -64,3 +64,4 @@ wgrad_slabs = int(_os.environ.get("AST_WGRAD_SLABS", "0"))
 # launches loses as well (2: 6.01 / 6.21 / 6.13, 3: 6.35, 4: 6.43; profiles/r03/ab_defer_streams.txt).
 wgrad_defer = _os.environ.get("AST_WGRAD_DEFER", "1") != "0"
 wgrad_defer_streams = int(_os.environ.get("AST_WGRAD_DEFER_STREAMS", "1"))   # streams per bank that share its deferred launches
+wgrad_defer_pool = _os.environ.get("AST_WGRAD_DEFER_POOL", "0") != "0"        # balance the deferred launches over ALL banks' flush streams

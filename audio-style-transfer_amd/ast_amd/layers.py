@@ -179,6 +179,8 @@ class WeightBank:
 
     def defer_conv_wgrad(self, dy, src, dwp, g, replicas, pw):
         self._conv_deferred.append((dy, src, dwp, g, replicas, pw))
+        if not any(b is self for b in _DeferPool.banks):
+            _DeferPool.banks.append(self)
 
     def note_slab(self, pw, slices):
         if any(p is pw for p, _ in self._slab_recs):
@@ -196,6 +198,15 @@ class WeightBank:
             sizes = (C.c_int64 * n)(*[pw.dwp.numel() // pw.replicas for pw, _ in part])
             slabs = (C.c_int32 * n)(*[sl for _, sl in part])
             check(lib().ast_slab_sum(bases, sizes, slabs, n, stream()), "ast_slab_sum")
+
+    def _side_stream(self, origin):
+        """This bank's flush stream, forked from `origin` once per parallel_flush() scope."""
+        if self._flush_stream is None:
+            self._flush_stream = torch.cuda.Stream(device=self.d_tiles.device)
+        if not any(s is self._flush_stream for s in _ParallelFlush.pending):
+            streams.fork(self._flush_stream, origin)
+            _ParallelFlush.pending.append(self._flush_stream)
+        return self._flush_stream
 
     def _launch_deferred(self, origin):
         """The deferred convolution weight gradients of this backward pass (config.wgrad_defer), longest first, spread over
@@ -243,13 +254,11 @@ class WeightBank:
                 _L.NEXT_BYTES = sum((e.dwp.numel() * 4 if e.dwp is not None else 0) + 3 * e.Co * e.Ci * e.KK * 4 for e in self.entries if e.dwp is not None)
             side, origin = None, torch.cuda.current_stream()
             if _ParallelFlush.active:
+                if config.wgrad_defer_pool and self._conv_deferred and len(_DeferPool.banks) > 1:
+                    _DeferPool.launch_all(origin)
                 # the banks' flushes touch disjoint, persistent buffers (staging arena, masters, flat gradient): inside
                 # parallel_flush() each bank's pair of kernels runs on its own stream and the context joins them
-                if self._flush_stream is None:
-                    self._flush_stream = torch.cuda.Stream(device=self.d_tiles.device)
-                side = self._flush_stream
-                streams.fork(side, torch.cuda.current_stream())
-                _ParallelFlush.pending.append(side)
+                side = self._side_stream(origin)
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 if self._conv_deferred:
                     self._launch_deferred(origin)
@@ -291,6 +300,40 @@ class _ParallelFlush:
     pending = []
 
 
+class _DeferPool:
+    """config.wgrad_defer_pool: the deferred weight gradients of ALL banks of a backward pass, longest first onto the least
+    loaded of the banks' flush streams (the banks differ in size: the last one used to run alone), launched by the first bank's
+    flush; the origin stream then waits for all of them and the banks' flush kernels follow it."""
+    banks = []
+
+    @staticmethod
+    def launch_all(origin):
+        banks, _DeferPool.banks = [b for b in _DeferPool.banks if b._conv_deferred], []
+        lanes = [b._side_stream(origin) for b in banks]
+        items = []
+        for bi, b in enumerate(banks):
+            items += [(bi, it) for it in b._conv_deferred]
+            b._conv_deferred = []
+        cost = lambda it: float(it[3].N) * it[3].Hm * it[3].Wm * max(it[3].Cd, 32) * max(it[3].ntaps * it[3].Cs, 64)
+        load = [0.0] * len(lanes)
+        for bi, it in sorted(items, key=lambda e: cost(e[1]), reverse=True):
+            i = load.index(min(load))
+            load[i] += cost(it)
+            dy, src, dwp, g, replicas, pw = it
+            dy.record_stream(lanes[i])
+            src.record_stream(lanes[i])
+            with torch.cuda.stream(lanes[i]):
+                ops._wgrad_launch(dy, src, dwp, g, replicas, pw)
+        # every bank's flush needs launches that ran on other banks' streams.  Mutual waits between the flush streams are the
+        # capture-crash shape of streams.py in its general form (A waits for B, then B waits for A: a stream waiting on a stream
+        # that already depends on it -- hipStreamEndCapture dumped core, gpurun_out/r3 run l), so the hand-over goes through the
+        # origin: it waits for all of them, they continue after it.
+        for st in lanes:
+            origin.wait_stream(st)
+        for st in lanes:
+            st.wait_stream(origin)
+
+
 @contextlib.contextmanager
 def parallel_flush():
     """Within this context the end-of-backward gradient flushes of different WeightBanks run on per-bank streams; leaving it
@@ -300,6 +343,7 @@ def parallel_flush():
         yield
         return
     _ParallelFlush.active, _ParallelFlush.pending = True, []
+    _DeferPool.banks = []
     try:
         yield
     finally:

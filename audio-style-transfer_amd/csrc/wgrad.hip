@@ -385,16 +385,19 @@ typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int row_swz(int r) { return (((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1; }
 
+template <int NST>
 __global__ __launch_bounds__(256, 2) void wgrad_rows_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ src, float* __restrict__ dw,
                                                             const ast_gather_t g, const int P, const int pps, const unsigned dy_bytes,
                                                             const unsigned src_bytes, const float rcp_hw, const float rcp_w, const int gx,
                                                             const int gy, const int gz, const int nrep, const long rep_stride) {
-  constexpr int NST = 4, RT = 4, CTW = 3;
+  constexpr int RT = 4, CTW = 3;
   constexpr int DYB = 64 * 128, XB = 72 * 128, MB = 3 * 64 * 2;      // dy lines, source lines (66 used), masks [kw][pixel] u16
+  static_assert(NST >= 2 && NST <= 4, "ring stages");
   constexpr int STAGE = DYB + XB + MB;
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) unsigned char wq_all[];
-  int* taptab = reinterpret_cast<int*>(wq_all + NST * STAGE);
+  constexpr int RING = NST * STAGE > 64 * 192 * 4 ? NST * STAGE : 64 * 192 * 4;      // the flush tile overlays the ring
+  int* taptab = reinterpret_cast<int*>(wq_all + RING);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_rows_kernel(const bf16_t* __rest
     xo[a] = (unsigned)((xgl[a] * g.Cs + cs0) * 2 + c * 16);
   }
   auto issue_tile = [&](int kt) __attribute__((always_inline)) {
-    unsigned char* st = wq_all + (kt & (NST - 1)) * STAGE;
+    unsigned char* st = wq_all + (kt % NST) * STAGE;
     const int adv = kt * 64;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_rows_kernel(const bf16_t* __rest
       const int h = fdiv(rem, W, rcp_w), w = rem - h * W;
       const bool hv = kh == 0 ? h >= 1 : (kh == 2 ? h <= H - 2 : true);
       const unsigned m0 = hv && w >= 1 ? 0xffffu : 0u, m1 = hv ? 0xffffu : 0u, m2 = hv && w <= W - 2 ? 0xffffu : 0u;
-      const unsigned ma = lds0 + (kt & (NST - 1)) * STAGE + DYB + XB + lane * 2;
+      const unsigned ma = lds0 + (kt % NST) * STAGE + DYB + XB + lane * 2;
       asm volatile("ds_write_b16 %0, %1\n\tds_write_b16 %0, %2 offset:128\n\tds_write_b16 %0, %3 offset:256" :: "v"(ma), "v"(m0), "v"(m1), "v"(m2) : "memory");
     }
   };
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_rows_kernel(const bf16_t* __rest
     __builtin_amdgcn_s_barrier();                   // every wave's pieces of tile kt are in LDS; stage (kt+3) % 4 (read in trip kt-1) is free
     asm volatile("" ::: "memory");
     WG_PH(1);
-    const unsigned st = lds0 + (kt & (NST - 1)) * STAGE;
+    const unsigned st = lds0 + (kt % NST) * STAGE;
     read_kstep(st, 0);
     if (kt + NST - 1 < nk) issue_tile(kt + NST - 1);
     wait_kstep(0);
@@ -609,12 +612,13 @@ bool wgrad_rows_eligible(const ast_gather_t& g, int dtype) {
   return true;
 }
 
+template <int NST>
 int launch_wgrad_rows(const void* dy, const void* src, float* dw, const ast_gather_t& g, int P, hipStream_t s) {
-  constexpr int LDS = 4 * (64 * 128 + 72 * 128 + 384) + 64;
-  static_assert(64 * 192 * 4 <= 4 * (64 * 128 + 72 * 128 + 384), "the flush tile overlays the ring");
+  constexpr int STAGE = 64 * 128 + 72 * 128 + 384;
+  constexpr int LDS = (NST * STAGE > 64 * 192 * 4 ? NST * STAGE : 64 * 192 * 4) + 64;
   static bool attr_set = false;
   if (!attr_set) {
-    AST_HIP(hipFuncSetAttribute((const void*)wgrad_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    AST_HIP(hipFuncSetAttribute((const void*)wgrad_rows_kernel<NST>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   const int gx = g.Cd / 64, gy = 3 * (g.Cs / 64);
@@ -630,7 +634,7 @@ int launch_wgrad_rows(const void* dy, const void* src, float* dw, const ast_gath
   const unsigned src_bytes = (unsigned)((size_t)P * g.Cs * 2);
   const int total = gx * gy * nsplit;
   g_wg_slices = nsplit;
-  hipLaunchKernelGGL(wgrad_rows_kernel, dim3((total + 7) / 8 * 8), dim3(256), LDS, s, (const bf16_t*)dy, (const bf16_t*)src, dw, g, P, pps,
+  hipLaunchKernelGGL(wgrad_rows_kernel<NST>, dim3((total + 7) / 8 * 8), dim3(256), LDS, s, (const bf16_t*)dy, (const bf16_t*)src, dw, g, P, pps,
                      dy_bytes, src_bytes, 1.0f / (float)(g.Hm * g.Wm), 1.0f / (float)g.Wm, gx, gy, nsplit, wg_nrep_arg(), g_wg_rep_stride);
   AST_CHECK_LAUNCH();
   return 0;
@@ -1251,7 +1255,11 @@ extern "C" int ast_wgrad(const void* dy, const void* src, float* dw, const ast_g
   const char* re = getenv("AST_WGRAD_ROWS");                 // read per call (host side only): tests toggle it at run time
   if (!(re && atoi(re) == 0) && wgrad_rows_eligible(g, dtype)) {
     if ((long)P * g.Cs * 2 >= (1L << 31)) AST_FAIL("ast_wgrad: source exceeds the 2 GiB buffer-addressing range");
-    return launch_wgrad_rows(dy, src, dw, g, P, s);
+    const char* se = getenv("AST_WGRAD_ROWS_STAGES");       // ring depth: 4 stages = 71 KB of LDS (two workgroups per CU), 3 = 53 KB (three)
+    const int nst = se ? atoi(se) : 4;
+    if (nst == 2) return launch_wgrad_rows<2>(dy, src, dw, g, P, s);
+    if (nst == 3) return launch_wgrad_rows<3>(dy, src, dw, g, P, s);
+    return launch_wgrad_rows<4>(dy, src, dw, g, P, s);
   }
   WHaloPlan whp;
   const bool halo = plan_wgrad_halo(g, dtype, nct, bmw, whp);

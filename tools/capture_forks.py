@@ -21,6 +21,8 @@ Patterns
   nested_via_main  the second-level stream is joined into the ORIGIN stream and the first-level stream then waits for the origin
   nested_helper    the nested pattern written with ast_amd.streams.fork / join (the guard routes the child's join through the origin)
   sibling       two first-level streams; one waits for an event of the other, both join the origin
+  sibling_mutual  two first-level streams wait for each other in turn: a waits for b, b then waits for a (b waits on a stream that
+             already depends on b -- the nested shape without a fork: what a pooled hand-over between flush streams does)
   tail       the side stream gets MORE work after its join event was recorded (an unjoined tail: what an autograd node that
              returns no gradient leaves behind when its backward runs on a side stream)
   unjoined   a forked stream is never joined (CUDA semantics: cudaErrorStreamCaptureUnjoined)
@@ -35,7 +37,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "audio-style-transfer_amd"))
 
-PATTERNS = ("seq", "fan", "keep", "nested", "nested_pre", "nested_fresh", "nested_direct", "nested_keep", "nested_via_main", "nested_helper", "sibling", "tail", "unjoined", "bwd", "bwd_leaf")
+PATTERNS = ("seq", "fan", "keep", "nested", "nested_pre", "nested_fresh", "nested_direct", "nested_keep", "nested_via_main", "nested_helper", "sibling", "sibling_mutual", "tail", "unjoined", "bwd", "bwd_leaf")
 
 
 def run_pattern(pattern, n):
@@ -178,6 +180,19 @@ def run_pattern(pattern, n):
                 main.wait_stream(a)
                 main.wait_stream(b)
             expect = [(i, i + 1.0) for i in range(n)] + [(n, float(n))]
+        elif pattern == "sibling_mutual":
+            a, b = sides[0], sides[1]
+            for i in range(n):
+                a.wait_stream(main)
+                b.wait_stream(main)
+                scale(x, bufs[i], i + 1, b)
+                a.wait_stream(b)                   # a now depends on b
+                scale(bufs[i], bufs[n], 1.0, a)
+                b.wait_stream(a)                   # ... and b waits for a
+                scale(bufs[n], bufs[n + 1], 1.0, b)
+                main.wait_stream(a)
+                main.wait_stream(b)
+            expect = [(i, i + 1.0) for i in range(n)] + [(n, float(n)), (n + 1, float(n))]
         elif pattern == "tail":
             s = sides[0]
             for i in range(n):

@@ -15,6 +15,8 @@ def label(name):
     if m:
         dt, slb, tm, tn = m.groups()
         return f"pconv_kernel<{'bf16' if dt == 'DF16b' else 'f32'},slab{slb}B,{int(tm) * 4}frag,{int(tn) * 16}ch>"
+    if "wgrad_rows_kernel" in name:              # the line-staged kernel of the 3x3 stride-1 layers: same family as the gathered one
+        return "wgrad_kernel<bf16,Cd64>"
     m = re.search(r"wgrad(_halo)?_kernelI(DF16b|f)Li(\d+)ELi\d+E", name)
     if m:
         return f"wgrad{m.group(1) or ''}_kernel<{'bf16' if m.group(2) == 'DF16b' else 'f32'},Cd{m.group(3)}>"
