@@ -89,6 +89,7 @@ _SIGS = {
     "ast_dropout_mask": ([vp, i64, f32, C.c_uint64, vp, vp], i32),
     "ast_mul": ([vp, vp, vp, i64, i32, vp], i32),
     "ast_recon_loss": ([vp, vp, i64, i32, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp], i32),
+    "ast_recon_loss_total": ([vp, vp, i64, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, vp, vp, vp], i32),
     "ast_infonce": ([vp, vp, i32, i32, f32, vp, vp, vp, vp], i32),
     "ast_margin": ([vp, i32, i32, f32, vp, vp, vp], i32),
     "ast_hsic": ([vp, vp, i32, i32, vp, vp, vp, vp, vp], i32),
@@ -147,6 +148,7 @@ CALL_BYTES = {
     "ast_chan_stats": lambda a: a[2] * a[3] * a[4] * _es(a[5]),
     # compute_comprehensive_loss: read output and target, write the gradient (f32)
     "ast_recon_loss": lambda a: 3 * 4 * a[3] * a[4] * 2 * a[5] * a[6],
+    "ast_recon_loss_total": lambda a: 3 * 4 * a[3] * a[4] * 2 * a[5] * a[6],
     "ast_adam": lambda a: 7 * 4 * a[4],                    # read p, g, m, v; write p, m, v
     "ast_sumsq": lambda a: 4 * a[1],
     "ast_weights_prepare_t": None,                         # bytes from NEXT_BYTES (WeightBank)

@@ -217,11 +217,10 @@ def _comprehensive_loss(output, target, lambda_temporal, lambda_phase, lambda_sp
     c = (mse_weight / (2 * n), 0.5 / n, lambda_phase / n,
          (lambda_temporal / (2 * B * (S - 1) * Freq * T)) if S > 1 else 0.0,
          (lambda_spectral / (2 * B * S * (Freq - 1) * T)) if Freq > 1 else 0.0)
-    total, sums = ops.ReconTotalFn.apply(output.contiguous(), target, c)
-    # the five reported components are sums * 1/count: one launch for all of them (they carry no gradient)
-    inv = ops.const_tensor((1.0 / (2 * n), 1.0 / n, 1.0 / n,
-                            1.0 / (2 * B * (S - 1) * Freq * T) if S > 1 else 0.0,
-                            1.0 / (2 * B * S * (Freq - 1) * T) if Freq > 1 else 0.0), torch.float32, output.device)
-    parts = ops.mul_const(sums.detach(), inv)
+    # the five reported components are sums * 1/count, formed by the same finishing launch as the total (they carry no gradient)
+    inv = (1.0 / (2 * n), 1.0 / n, 1.0 / n,
+           1.0 / (2 * B * (S - 1) * Freq * T) if S > 1 else 0.0,
+           1.0 / (2 * B * S * (Freq - 1) * T) if Freq > 1 else 0.0)
+    total, _, parts = ops.ReconTotalFn.apply(output.contiguous(), target, c, inv)
     return {"total_loss": total, "mse_loss": parts[0], "mag_loss": parts[1], "phase_loss": parts[2],
             "temporal_loss": parts[3], "spectral_loss": parts[4]}

@@ -1288,30 +1288,33 @@ def weighted_sum(weights, pairs):
 
 
 class ReconTotalFn(torch.autograd.Function):
-    """compute_comprehensive_loss (new_decoder.py:348-420) in one pass: returns
-    (total, raw sums[5]) and keeps d total / d out computed in the same pass."""
+    """compute_comprehensive_loss (new_decoder.py:348-420) in one pass plus a finishing launch: returns (total, raw sums[5],
+    reported means[5] = inv * sums) and keeps d total / d out computed in the same pass."""
 
     @staticmethod
-    def forward(ctx, out, tgt, coefs):
+    def forward(ctx, out, tgt, coefs, inv):
+        import ctypes as C
         B, S, Cc, T, Fq = out.shape
         assert Cc == 2 and out.is_contiguous() and out.dtype == torch.float32
         assert tgt.shape == out.shape and tgt.dtype == torch.float32 and tgt.stride(4) == 1
         ld = tgt.stride(3)
         assert tgt.stride(2) == T * ld and tgt.stride(1) == 2 * T * ld and tgt.stride(0) == S * 2 * T * ld, \
             "target must be a [..., :F] slice of a contiguous tensor"
-        sums = torch.empty(5, dtype=torch.float32, device=out.device)
+        ws = torch.empty(64 * 5, dtype=torch.float32, device=out.device)          # AST_RECON_SLOTS rows of partial sums
+        res = torch.empty(11, dtype=torch.float32, device=out.device)
         grad = torch.empty_like(out)
-        check(lib().ast_recon_loss(ptr(out), ptr(tgt), ld, B, S, T, Fq, *[float(c) for c in coefs], ptr(sums), ptr(grad),
-                                   stream()), "ast_recon_loss")
+        c5, i5 = (C.c_float * 5)(*[float(c) for c in coefs]), (C.c_float * 5)(*[float(c) for c in inv])
+        check(lib().ast_recon_loss_total(ptr(out), ptr(tgt), ld, B, S, T, Fq, c5, i5, ptr(ws), ptr(res), ptr(grad), stream()),
+              "ast_recon_loss_total")
         ctx.save_for_backward(grad)
-        ctx.mark_non_differentiable(sums)
-        total = (sums * const_tensor(tuple(float(c) for c in coefs), torch.float32, out.device)).sum()
-        return total, sums
+        total, sums, parts = res[5], res[:5], res[6:]
+        ctx.mark_non_differentiable(sums, parts)
+        return total, sums, parts
 
     @staticmethod
-    def backward(ctx, gtotal, gsums):
+    def backward(ctx, gtotal, gsums, gparts):
         (grad,) = ctx.saved_tensors
-        return _scaled(grad, gtotal), None, None
+        return _scaled(grad, gtotal), None, None, None
 
 
 class InfoNCEFn(torch.autograd.Function):

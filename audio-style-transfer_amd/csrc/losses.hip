@@ -13,7 +13,7 @@ constexpr float PI_F = 3.14159265358979323846f;
 // differences stay in registers; t+-1 neighbours come from L1/L2.
 __global__ __launch_bounds__(1024) void recon_loss_kernel(const float* __restrict__ out, const float* __restrict__ tgt, int64_t tld,
                                                           int B, int S, int T, int Fq, float c_mse, float c_mag, float c_ph,
-                                                          float c_tmp, float c_spc, float* __restrict__ sums, float* __restrict__ grad) {
+                                                          float c_tmp, float c_spc, float* __restrict__ sums, float* __restrict__ grad, int nslots) {
   __shared__ float red[17];
   const unsigned total = (unsigned)B * T * Fq;                  // < 2^31 (host check): 32-bit index math, no 64-bit divisions
   const size_t plane_o = (size_t)T * Fq, plane_t = (size_t)T * tld;
@@ -67,8 +67,24 @@ __global__ __launch_bounds__(1024) void recon_loss_kernel(const float* __restric
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const float v = block_sum(acc[k], red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(sums + k, v);
+    if (threadIdx.x == 0) unsafeAtomicAdd(sums + (blockIdx.x % nslots) * 5 + k, v);      // nslots rows of 5: few adders per address
   }
+}
+
+// sums[k] = sum over the slots (fixed order), total = sum_k c[k] * sums[k], parts[k] = inv[k] * sums[k]: out = [5 sums][total][5 parts]
+struct ReconFin { float c[5], inv[5]; };
+__global__ __launch_bounds__(64) void recon_finish_kernel(const float* __restrict__ ws, int nslots, ReconFin a, float* __restrict__ out) {
+  __shared__ float sk[5];
+  const int k = threadIdx.x;
+  if (k < 5) {
+    float v = 0.f;
+    for (int i = 0; i < nslots; ++i) v += ws[i * 5 + k];
+    sk[k] = v;
+    out[k] = v;
+    out[6 + k] = v * a.inv[k];
+  }
+  __syncthreads();
+  if (k == 0) out[5] = (((a.c[0] * sk[0] + a.c[1] * sk[1]) + a.c[2] * sk[2]) + a.c[3] * sk[3]) + a.c[4] * sk[4];
 }
 
 // ---- InfoNCE (losses.py:9-36), one workgroup of 1024 -------------------------------
@@ -372,7 +388,28 @@ extern "C" int ast_recon_loss(const float* out, const float* tgt, int64_t tgt_ld
   static const int max_blocks = getenv("AST_RECON_BLOCKS") ? atoi(getenv("AST_RECON_BLOCKS")) : 256;
   const int grid = (int)std::min<size_t>((total + 1023) / 1024, (size_t)std::max(1, max_blocks));
   hipLaunchKernelGGL(recon_loss_kernel, dim3(grid), dim3(1024), 0, s, out, tgt, tgt_ld, B, S, T, Fq, c_mse, c_mag, c_phase, c_temporal,
-                     c_spectral, sums, grad);
+                     c_spectral, sums, grad, 1);
+  AST_CHECK_LAUNCH();
+  return 0;
+}
+
+// One thread per (b, t, f) bin (256-thread workgroups: every load of the pass in flight at once instead of 4-5 dependent trips per
+// thread), the workgroups' five partial sums added into AST_RECON_SLOTS rows (72 adders per address instead of 4 608), and a
+// finishing launch that reduces the rows in a fixed order and forms the weighted total and the five reported means -- which took
+// three element-wise launches behind the 256-workgroup pass (47.9 us on the step's chain).
+extern "C" int ast_recon_loss_total(const float* out, const float* tgt, int64_t tgt_ld, int B, int S, int T, int Fq, const float* coef5,
+                                    const float* inv5, float* ws, float* res11, float* grad, void* stream) {
+  if (!out || !tgt || !coef5 || !inv5 || !ws || !res11 || B <= 0 || S <= 0 || T <= 0 || Fq <= 0 || tgt_ld < Fq) AST_FAIL("ast_recon_loss_total: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  AST_HIP(hipMemsetAsync(ws, 0, AST_RECON_SLOTS * 5 * sizeof(float), s));
+  const size_t total = (size_t)B * T * Fq;
+  if (total >= (1ull << 31)) AST_FAIL("ast_recon_loss_total: more than 2^31 bins per section");
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);
+  hipLaunchKernelGGL(recon_loss_kernel, dim3(grid), dim3(256), 0, s, out, tgt, tgt_ld, B, S, T, Fq, coef5[0], coef5[1], coef5[2], coef5[3],
+                     coef5[4], ws, grad, AST_RECON_SLOTS);
+  ReconFin a;
+  for (int k = 0; k < 5; ++k) { a.c[k] = coef5[k]; a.inv[k] = inv5[k]; }
+  hipLaunchKernelGGL(recon_finish_kernel, dim3(1), dim3(64), 0, s, ws, AST_RECON_SLOTS, a, res11);
   AST_CHECK_LAUNCH();
   return 0;
 }

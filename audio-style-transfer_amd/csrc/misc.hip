@@ -140,19 +140,44 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, T* __restrict_
     const int olo_h = max(0, (int)floorf((h - 1 + 0.5f) / sh - 0.5f) - 1), ohi_h = min(Ho - 1, (int)ceilf((h + 1 + 0.5f) / sh - 0.5f) + 1);
     const int olo_w = max(0, (int)floorf((w - 1 + 0.5f) / sw - 0.5f) - 1), ohi_w = min(Wo - 1, (int)ceilf((w + 1 + 0.5f) / sw - 0.5f) + 1);
     float a0 = 0.f, a1 = 0.f;   // C <= 2 (real / imaginary planes)
+    // the column weights do not depend on the output row: computed once per pixel (up to 10 candidate columns in registers; the
+    // 5 x 5 candidate window used to evaluate bil_src 30 times per pixel -- 32 us on the step's chain for a 1:1 resize)
+    constexpr int MAXC = 10;
+    const int ncw = ohi_w - olo_w + 1;
+    float cwv[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      cwv[k] = 0.f;
+      if (k < ncw) {
+        int w0, w1; float lw;
+        bil_src(olo_w + k, sw, W, w0, w1, lw);
+        cwv[k] = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+      }
+    }
     for (int oh = olo_h; oh <= ohi_h; ++oh) {
       int h0, h1; float lh;
       bil_src(oh, sh, H, h0, h1, lh);
       const float ch = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
       if (ch == 0.f) continue;
-      for (int ow = olo_w; ow <= ohi_w; ++ow) {
-        int w0, w1; float lw;
-        bil_src(ow, sw, W, w0, w1, lw);
-        const float cw = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
-        if (cw == 0.f) continue;
-        const size_t o = (size_t)oh * Wo + ow;
-        a0 += ch * cw * dy[((size_t)n * C + 0) * Ho * Wo + o];
-        if (C > 1) a1 += ch * cw * dy[((size_t)n * C + 1) * Ho * Wo + o];
+      const float* r0 = dy + ((size_t)n * C + 0) * Ho * Wo + (size_t)oh * Wo + olo_w;
+      const float* r1 = r0 + (size_t)Ho * Wo;
+      if (ncw <= MAXC) {
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {
+          if (k < ncw && cwv[k] != 0.f) {
+            a0 += ch * cwv[k] * r0[k];
+            if (C > 1) a1 += ch * cwv[k] * r1[k];
+          }
+        }
+      } else {
+        for (int ow = olo_w; ow <= ohi_w; ++ow) {
+          int w0, w1; float lw;
+          bil_src(ow, sw, W, w0, w1, lw);
+          const float cw = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+          if (cw == 0.f) continue;
+          a0 += ch * cw * r0[ow - olo_w];
+          if (C > 1) a1 += ch * cw * r1[ow - olo_w];
+        }
       }
     }
     for (int u = 0; u < Cp; u += 8) {

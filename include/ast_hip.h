@@ -309,6 +309,12 @@ int ast_mul(const void* a, const float* mask, void* y, int64_t n, int dtype, voi
 int ast_recon_loss(const float* out, const float* tgt, int64_t tgt_ld, int B, int S, int T, int Fq,
                    float w_mse, float w_mag, float w_phase, float w_temporal, float w_spectral,
                    float* sums, float* grad, void* stream);
+/* ast_recon_loss with the weighted total and the reported means formed on the device: coef5 / inv5 are HOST arrays (the five weights
+ * c_mse .. c_spectral and the five 1/count factors of new_decoder.py:402-418), ws is AST_RECON_SLOTS x 5 floats of scratch (zeroed by
+ * the call), res11 receives [5 raw sums][total = sum_k coef5[k] * sums[k]][5 means = inv5[k] * sums[k]].  grad as in ast_recon_loss. */
+#define AST_RECON_SLOTS 64
+int ast_recon_loss_total(const float* out, const float* tgt, int64_t tgt_ld, int B, int S, int T, int Fq, const float* coef5,
+                         const float* inv5, float* ws, float* res11, float* grad, void* stream);
 /* losses.py on (B,256) embeddings; each writes loss[0] and optional gradients */
 int ast_infonce(const float* emb, const int32_t* labels, int B, int D, float temperature,
                 float* loss, float* demb, float* ws /* 2*B*B + B floats */, void* stream);

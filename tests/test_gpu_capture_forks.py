@@ -21,6 +21,8 @@ def _run(pattern, n):
 # NOT in this list, on purpose: "nested" (a forked stream waits for an event of its own child stream), which segfaults inside
 # hipStreamEndCapture on ROCm 7.2 (tools/capture_forks.py nested 4 / 16; profiles/r03/capture_forks_*.txt).  "nested_helper" is the
 # same dependency structure written with ast_amd.streams.join, which routes that join through the capture's origin stream.
+# "sibling_mutual" (a waits for b, then b waits for a) is the same shape without a fork and crashes the same way
+# (profiles/r03/capture_forks_mutual.txt): hand-overs between side streams go through the origin (layers._DeferPool).
 @pytest.mark.parametrize("pattern,n", [("seq", 32), ("fan", 24), ("keep", 24), ("nested_direct", 16), ("nested_via_main", 16), ("nested_helper", 16),
                                        ("sibling", 16), ("bwd", 32), ("bwd_leaf", 32)])
 def test_joined_fork_patterns_capture_and_replay(pattern, n):

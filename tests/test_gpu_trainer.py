@@ -73,6 +73,33 @@ def test_trainer_modes_agree():
         assert math.isclose(a, ref_abs, rel_tol=1e-6), (mode, a, ref_abs)
 
 
+def test_weight_gradient_scheduling_modes_agree():
+    """Where the convolution weight gradients are LAUNCHED must not change the step: inside each layer's backward node (the
+    reference order), deferred to the banks' end-of-backward flush (the default), pooled over all banks' flush streams, on their
+    own stream beside the data-gradient chain, and with the slab flush -- eager and as a captured graph."""
+    from ast_amd import config
+    saved = (config.wgrad_defer, config.wgrad_defer_pool, config.wgrad_slabs, os.environ.get("AST_WGRAD_STREAM"))
+    try:
+        config.wgrad_defer, config.wgrad_defer_pool, config.wgrad_slabs = False, False, 0
+        ref_hist, _, ref_abs, _ = _run(False, True)
+        tols = _noise_tolerances(ref_hist, _run(False, True)[0])
+        for name, defer, pool, slabs, wstream in (("deferred", True, False, 0, None), ("pooled", True, True, 0, None),
+                                                   ("deferred+slabs", True, False, 128, None), ("side stream", False, False, 0, "1")):
+            config.wgrad_defer, config.wgrad_defer_pool, config.wgrad_slabs = defer, pool, slabs
+            os.environ.pop("AST_WGRAD_STREAM", None)
+            if wstream:
+                os.environ["AST_WGRAD_STREAM"] = wstream
+            for use_graph in (False, True):
+                hist, _, a, _ = _run(use_graph, True)
+                _assert_close_hist(hist, ref_hist, tols, (name, use_graph))
+                assert math.isclose(a, ref_abs, rel_tol=1e-6), (name, use_graph, a, ref_abs)
+    finally:
+        config.wgrad_defer, config.wgrad_defer_pool, config.wgrad_slabs = saved[:3]
+        os.environ.pop("AST_WGRAD_STREAM", None)
+        if saved[3] is not None:
+            os.environ["AST_WGRAD_STREAM"] = saved[3]
+
+
 def test_loss_goes_down_on_a_fixed_batch():
     ast_amd.set_compute_dtype(torch.float32)
     cfg = train.TrainConfig(use_graph=True, dropout=False, lr_g=2e-4, use_adv=False, use_hsic=False, use_nce=False)
