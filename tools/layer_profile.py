@@ -4,7 +4,8 @@ import sys, os, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "audio-style-transfer_amd")); sys.path.insert(0, ROOT)
 import torch, ast_amd
-from ast_amd import ops, train
+from ast_amd import config, ops, train
+config.wgrad_defer = False          # time every weight gradient where its layer's backward node launches it
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
 ast_amd.set_compute_dtype(dt)
 tr = train.Trainer(train.TrainConfig(use_graph=False))
@@ -18,9 +19,9 @@ def ig(src, wgt, bias, dst, g, flags=0, stats=None, bn=None, per_image=False):
     e0.record(); orig_ig(src, wgt, bias, dst, g, flags, stats, bn, per_image); e1.record()
     M = g.N*g.Hm*g.Wm
     recs.append(("igemm " + ops._igemm_config(g, ops.dcode(src.dtype)) + (" f32" if src.dtype == torch.float32 else ""), M, g.Cd, g.ntaps*g.Cs, g.ntaps, ops._gemm_cost(g, src.element_size()), e0, e1))
-def wg(dy, src, dwp, g, replicas=1):
+def wg(dy, src, dwp, g, replicas=1, pw=None):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); orig_wg(dy, src, dwp, g, replicas); e1.record()
+    e0.record(); orig_wg(dy, src, dwp, g, replicas, pw); e1.record()
     M = g.N*g.Hm*g.Wm
     recs.append(("wgrad" + (" f32" if src.dtype == torch.float32 else ""), M, g.Cd, g.ntaps*g.Cs, g.ntaps, ops._gemm_cost(g, src.element_size(), True), e0, e1))
 ops._igemm, ops._wgrad = ig, wg
