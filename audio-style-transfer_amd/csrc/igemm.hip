@@ -606,7 +606,7 @@ __device__ unsigned long long ast_stamps[16384 * 8];
 #else
 #define PC_STAMP(k) do { } while (0)
 #endif
-struct PconvPlan { int TH, TWF, PH, PW, dhmin, dwmin, tiles_h, tiles_w, nct, lds, rows, tm; unsigned m_nct, m_per_img, m_tiles_w, m_pw20, m_twf, m_twf20; unsigned long long tapq[3]; };
+struct PconvPlan { int TH, TWF, PH, PW, dhmin, dwmin, tiles_h, tiles_w, nct, lds, rows, tm, wall; unsigned m_nct, m_per_img, m_tiles_w, m_pw20, m_twf, m_twf20; unsigned long long tapq[3]; };
 // Division by a run-time constant d through m = ceil(2^32 / d): floor(n / d) = umulhi(n, m), exact while n * d < 2^32
 // (plan_pconv checks).  On wave-uniform operands it is ONE scalar instruction (s_mul_hi_u32); the float-reciprocal fdiv the
 // gathered kernels use is ~12 VALU even for scalars, and the four waves of a SIMD all run this prologue at the same time.
@@ -642,8 +642,13 @@ __device__ __forceinline__ void pc_store4(__amdgpu_buffer_rsrc_t r, unsigned vof
   }
 }
 
-template <typename T, int SLB, int TM, int TN>
-__global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(const T* __restrict__ src, const T* __restrict__ wgt, const float* __restrict__ bias,
+// WALL ("weights of all taps"): the per-tap weight stage above costs one workgroup barrier and one exposed weight-load latency
+// per tap for TM*TN*KS MFMAs per wave -- 12 of them (192 cycles) on the 512-channel layer, where a tap step measures ~800 cycles.
+// With WALL the weights of ALL taps of a channel slab sit in LDS beside the patch (ntaps x BN x SLB bytes), the next slab's patch
+// and weights are fetched into registers while this slab's ntaps x TM x TN x KS MFMAs run, and a slab costs two barriers
+// (hand-over of the registers to LDS) instead of ntaps.
+template <typename T, int SLB, int TM, int TN, bool WALL>
+__global__ __launch_bounds__(256, (WALL ? 2 : (TM * TN <= 8 ? 4 : 2))) void pconv_kernel(const T* __restrict__ src, const T* __restrict__ wgt, const float* __restrict__ bias,
                                                     T* __restrict__ dst, const ast_gather_t g, const PconvPlan pp, const int flags,
                                                     float* __restrict__ ws, const unsigned src_bytes, const unsigned wgt_bytes,
                                                     const T* __restrict__ bn_x, const float* __restrict__ bn_scale,
@@ -758,6 +763,62 @@ __global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(cons
 
   PC_STAMP(1);
   const int nslab = (g.Cs * ES) / SLB;
+  if constexpr (WALL) {
+    u32x4 pr[PC_MAXPL], wra[AST_MAX_TAPS][NWL];
+    auto fetch = [&](int s) __attribute__((always_inline)) {
+      const unsigned sb = (unsigned)(s * SLB);
+#pragma unroll
+      for (int i = 0; i < PC_MAXPL; ++i) pr[i] = __builtin_amdgcn_raw_buffer_load_b128(srcR, goff[i] + sb, 0, 0);
+#pragma unroll
+      for (int t = 0; t < AST_MAX_TAPS; ++t)
+        if (t < g.ntaps) {
+          const unsigned w0 = (tap_entry(t) >> 12) * wslice + sb;
+#pragma unroll
+          for (int k = 0; k < NWL; ++k) wra[t][k] = __builtin_amdgcn_raw_buffer_load_b128(wgtR, woff[k] + w0, 0, 0);
+        }
+    };
+    fetch(0);
+    for (int s = 0; s < nslab; ++s) {
+      // (the previous slab ended with a barrier: every read of the patch and of the weights is done)
+#pragma unroll
+      for (int i = 0; i < PC_MAXPL; ++i)
+        if (p0 + i * PSTEP < npix) *reinterpret_cast<u32x4*>(pl + l0 + i * (PSTEP * SLB)) = pr[i];
+#pragma unroll
+      for (int t = 0; t < AST_MAX_TAPS; ++t)
+        if (t < g.ntaps) {
+#pragma unroll
+          for (int k = 0; k < NWL; ++k)
+            if (wl[k] >= 0) *reinterpret_cast<u32x4*>(wbuf + t * (BN * SLB) + wl[k]) = wra[t][k];
+        }
+      __syncthreads();
+      if (s == 0) PC_STAMP(2);
+      if (s + 1 < nslab) fetch(s + 1);              // in flight under this slab's MFMAs
+      __builtin_amdgcn_sched_barrier(0);            // (keep the loads here: the scheduler would sink them to their first use)
+      for (int t = 0; t < g.ntaps; ++t) {
+        const int toff = (int)(tap_entry(t) & 0xfffu);
+        const unsigned char* wcur = wbuf + t * (BN * SLB);
+        int xa[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const int p = pb[j] + toff;
+          xa[j] = p * SLB + ((fq ^ pc_h<SLB>(p)) << 4);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          frag wf[TN], xf[TM];
+#pragma unroll
+          for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const frag*>(wcur + (aoff[i] ^ (ks << 6)));
+#pragma unroll
+          for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const frag*>(pl + (xa[j] ^ (ks << 6)));
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+        }
+      }
+      __syncthreads();
+    }
+  } else {
   u32x4 wr[NWL];
   for (int s = 0; s < nslab; ++s) {
     const unsigned sb = (unsigned)(s * SLB);
@@ -814,6 +875,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 8 ? 4 : 2)) void pconv_kernel(cons
       }
       __syncthreads();
     }
+  }
   }
 
   PC_STAMP(3);
@@ -960,12 +1022,36 @@ bool plan_pconv(const ast_gather_t& g, int dtype, PconvPlan& pp, int& slb, int& 
       const double eff = (double)g.Hm * g.Wm / ((double)tiles_h * nf * 16.0) - 1e-3 * (ph * pw) / 180.0 - 0.02;   // prefer 2-D tiles on a tie
       if (eff > best) { best = eff; pp.rows = 1; pp.tm = nf / 4; pp.TH = th; pp.TWF = 1; pp.PH = ph; pp.PW = pw; pp.tiles_h = tiles_h; pp.tiles_w = 1; }
     }
+  // tiny images (5x10: the last block): one 4-fragment tile per image, only where nothing larger fits
+  if (best < 0.6 && slb == 128)
+    for (int th = 1; th * g.Wm <= 64 && th <= g.Hm; ++th) {
+      const int ph = th + (dhmax - dhmin), pw = g.Wm + (dwmax - dwmin);
+      if (ph * pw > max_px) continue;
+      const int tiles_h = (g.Hm + th - 1) / th;
+      const double eff = (double)g.Hm * g.Wm / ((double)tiles_h * 64.0) - 1e-3 * (ph * pw) / 180.0 - 0.02;
+      if (eff > best) { best = eff; pp.rows = 1; pp.tm = 1; pp.TH = th; pp.TWF = 1; pp.PH = ph; pp.PW = pw; pp.tiles_h = tiles_h; pp.tiles_w = 1; }
+    }
   if (best < 0.6) return false;
   pp.dhmin = dhmin; pp.dwmin = dwmin;
   const long spatial = (long)g.N * pp.tiles_h * pp.tiles_w;
   if (tn == 4 && spatial * ((g.Cd + 63) / 64) < 200) tn = 2;      // few tiles: 32-channel tiles double the workgroups
+  // WALL (see the kernel): all taps' weights of a slab resident, the next slab prefetched under this slab's MFMAs.  It pays where
+  // the per-tap steps are short AND there are slabs to overlap: >= 4 channel slabs, with 32-channel tiles so that two workgroups
+  // still share a CU (<= 80 KB).  Isolated, 512 channels: 39.7 -> 26.2 us (492 TF/s); forced onto the 64 / 128 / 256-channel layers
+  // with their 64-channel tiles (one workgroup per CU, one or two slabs) it loses: 28.0 -> 51.9, 23.2 -> 32.3, 30.7 -> 44.1 us
+  // (profiles/r03/pconv_wall_layers.txt).  AST_PCONV_WALL = 0: off, 1: wherever it fits, 2: wherever it fits with 32-channel tiles.
+  {
+    const char* we = getenv("AST_PCONV_WALL");
+    const int mode = we ? atoi(we) : -1, nslab = rowb / slb;
+    const int patch = pp.PH * pp.PW * slb;
+    pp.wall = 0;
+    if (dtype == AST_BF16 && g.ntaps >= 3 && mode != 0) {
+      if (mode == 1) pp.wall = patch + g.ntaps * tn * 16 * slb <= 150 * 1024;
+      else if ((mode == 2 || nslab >= 4) && patch + g.ntaps * 32 * slb <= 80 * 1024) { pp.wall = 1; tn = 2; }
+    }
+    pp.lds = patch + (pp.wall ? g.ntaps : 2) * tn * 16 * slb;
+  }
   pp.nct = (g.Cd + tn * 16 - 1) / (tn * 16);
-  pp.lds = pp.PH * pp.PW * slb + 2 * tn * 16 * slb;
   pp.tapq[0] = pp.tapq[1] = pp.tapq[2] = 0;
   for (int t = 0; t < g.ntaps; ++t) {
     const int dh = (g.tap[t] & 255) - 64, dw = ((g.tap[t] >> 8) & 255) - 64, wt = g.tap[t] >> 16;
@@ -982,15 +1068,15 @@ bool plan_pconv(const ast_gather_t& g, int dtype, PconvPlan& pp, int& slb, int& 
   const char* mt = getenv("AST_PCONV_MIN_TILES");
   const long min_tiles = mt ? atol(mt) : 192;
   if (spatial * pp.nct < min_tiles) return false;                 // under-filled grids keep the K-split plans
-  return pp.lds <= 64 * 1024;
+  return pp.lds <= (pp.wall ? 150 : 64) * 1024;
 }
 
-template <typename T, int SLB, int TM, int TN>
+template <typename T, int SLB, int TM, int TN, bool WALL>
 int launch_pconv(const void* src, const void* wgt, const float* bias, void* dst, const ast_gather_t& g, const PconvPlan& pp, int flags,
                  float* ws, const void* bn_x, const float* bn_scale, const float* bn_shift, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    AST_HIP(hipFuncSetAttribute((const void*)pconv_kernel<T, SLB, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    AST_HIP(hipFuncSetAttribute((const void*)pconv_kernel<T, SLB, TM, TN, WALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (WALL ? 150 : 64) * 1024));
     attr_set = true;
   }
   const int tiles = g.N * pp.tiles_h * pp.tiles_w * pp.nct;
@@ -1000,7 +1086,7 @@ int launch_pconv(const void* src, const void* wgt, const float* bias, void* dst,
   // registers -- measured SLOWER, 41 -> 54 us on the 64->64-channel layer: the prefetch registers cost a wave per SIMD,
   // and what the kernel lacks is overlap between workgroups, not bandwidth)
   const int grid = (tiles + 7) / 8 * 8;
-  hipLaunchKernelGGL((pconv_kernel<T, SLB, TM, TN>), dim3(grid), dim3(256), pp.lds, s, (const T*)src, (const T*)wgt, bias, (T*)dst,
+  hipLaunchKernelGGL((pconv_kernel<T, SLB, TM, TN, WALL>), dim3(grid), dim3(256), pp.lds, s, (const T*)src, (const T*)wgt, bias, (T*)dst,
                      g, pp, flags, ws, src_bytes, wgt_bytes, (const T*)bn_x, bn_scale, bn_shift);
   AST_CHECK_LAUNCH();
   return 0;
@@ -1182,8 +1268,10 @@ extern "C" int ast_igemm_bn(const void* src, const void* wgt, const float* bias,
       if ((flags & 16) && ((flags & 11) || !ws || ws_floats < (stat_slot_mask(flags) + 1L) * g.Cd * 3 || !bn_x || !bn_scale || !bn_shift))
         AST_FAIL("ast_igemm: fused BatchNorm-backward sums need plain stores, a zeroed [64][Cd][3] table and the layer's x / scale / shift");
       if ((flags & 8) && ((flags & 3) || !ws || ws_floats < ((flags & 64) ? (long)g.N : stat_slot_mask(flags) + 1L) * g.Cd * 2)) AST_FAIL("ast_igemm: fused channel statistics need plain stores and a zeroed [64][Cd][2] (per image: [N][Cd][2]) table");
-#define AST_PC(S_, M_, N_) return launch_pconv<T, S_, M_, N_>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s)
+#define AST_PC(S_, M_, N_) do { if (pp.wall) return launch_pconv<T, S_, M_, N_, true>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s); \
+                                return launch_pconv<T, S_, M_, N_, false>(src, wgt, bias, dst, g, pp, flags, ws, bn_x, bn_scale, bn_shift, s); } while (0)
       AST_DISPATCH_T(dtype, {
+        if (slb == 128 && pp.tm == 1) { if (tn == 4) AST_PC(128, 1, 4); AST_PC(128, 1, 2); }
         if (slb == 128 && pp.tm == 2) { if (tn == 4) AST_PC(128, 2, 4); AST_PC(128, 2, 2); }
         if (slb == 128) { if (tn == 4) AST_PC(128, 3, 4); AST_PC(128, 3, 2); }
         if (pp.tm == 2) { if (tn == 4) AST_PC(64, 2, 4); AST_PC(64, 2, 2); }
