@@ -212,3 +212,42 @@ def test_igemm_argument_validation_returns_error_codes():
     assert igemm_bn(gp, 16, fake, 64 * 64 * 3, sf=None) != 0
     # null geometry / tensors
     assert lib.ast_igemm(None, fake, None, fake, gg, bf16, 0, None, 0, None) != 0
+
+
+def test_round3_entry_points_refuse_bad_arguments():
+    """The entry points added in round 3 validate before they launch: null pointers, counts beyond the fixed kernel-argument
+    tables, misaligned slab records.  Every call below returns an error code on the host (fake pointers are never dereferenced)."""
+    import ctypes
+    lib = _lib.lib()
+    fake = 0x10000
+    f5 = (ctypes.c_float * 5)(1, 1, 1, 1, 1)
+    # ast_recon_loss_total: scratch / result / coefficient arrays are required, the target's row stride covers its bins
+    rl = lambda out=fake, tgt=fake, ld=513, c=f5, i=f5, ws=fake, res=fake: lib.ast_recon_loss_total(out, tgt, ld, 2, 2, 8, 513, c, i, ws, res, None, None)
+    assert rl(ws=None) != 0 and b"ast_recon_loss_total" in lib.ast_last_error()
+    assert rl(res=None) != 0 and rl(out=None) != 0 and rl(c=None) != 0 and rl(i=None) != 0
+    assert rl(ld=512) != 0
+    # ast_set_values / ast_weighted_sum: at most AST_MAX_STEP_SCALARS (16) values / terms, all travelling as kernel arguments
+    vals = (ctypes.c_float * 17)(*range(17))
+    assert lib.ast_set_values(fake, vals, 17, None) != 0 and lib.ast_set_values(fake, vals, 0, None) != 0 and lib.ast_set_values(None, vals, 4, None) != 0
+    terms = (ctypes.c_void_p * 17)(*([fake] * 17))
+    widx = (ctypes.c_int32 * 17)(*([0] * 17))
+    assert lib.ast_weighted_sum(terms, widx, 17, fake, fake, None) != 0
+    widx[1] = 16
+    assert lib.ast_weighted_sum(terms, widx, 2, fake, fake, None) != 0          # weight index outside the scalar table
+    terms[0] = None
+    widx[1] = 0
+    assert lib.ast_weighted_sum(terms, widx, 2, fake, fake, None) != 0          # null term
+    # ast_slab_sum: 1..48 records, 16-byte aligned bases, copies of a multiple of 4 floats
+    bases = (ctypes.c_void_p * 2)(fake, fake + 4)
+    sizes = (ctypes.c_int64 * 2)(64, 64)
+    cnt = (ctypes.c_int32 * 2)(2, 2)
+    assert lib.ast_slab_sum(bases, sizes, cnt, 0, None) != 0 and lib.ast_slab_sum(bases, sizes, cnt, 49, None) != 0
+    assert lib.ast_slab_sum(bases, sizes, cnt, 2, None) != 0 and b"aligned" in lib.ast_last_error()
+    sizes[0] = 6
+    assert lib.ast_slab_sum(bases, sizes, cnt, 1, None) != 0
+    # ast_wgrad_slab: slab count and the slices output
+    g, _ = ops.gather_direct(2, 8, 8, 64, 64, 3, 1, 1)
+    sl = ctypes.c_int32(0)
+    assert lib.ast_wgrad_slab(fake, fake, fake, g, _lib.BF16, 0, ctypes.byref(sl), None) != 0
+    assert lib.ast_wgrad_slab(fake, fake, fake, g, _lib.BF16, 4, None, None) != 0
+    assert lib.ast_wgrad_slab(None, fake, fake, g, _lib.BF16, 4, ctypes.byref(sl), None) != 0      # (ast_wgrad's own null check)
