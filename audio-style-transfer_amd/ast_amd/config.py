@@ -64,4 +64,9 @@ wgrad_slabs = int(_os.environ.get("AST_WGRAD_SLABS", "0"))
 # launches loses as well (2: 6.01 / 6.21 / 6.13, 3: 6.35, 4: 6.43; profiles/r03/ab_defer_streams.txt).
 wgrad_defer = _os.environ.get("AST_WGRAD_DEFER", "1") != "0"
 wgrad_defer_streams = int(_os.environ.get("AST_WGRAD_DEFER_STREAMS", "1"))   # streams per bank that share its deferred launches
-wgrad_defer_pool = _os.environ.get("AST_WGRAD_DEFER_POOL", "0") != "0"        # balance the deferred launches over ALL banks' flush streams
+# Balance the deferred launches over the banks' flush streams (the smallest bank's stream takes over the larger banks' cheapest
+# launches after its own flush; one-directional waits).  Opt-in: 6.06 / 6.07 / 6.02 ms without against 6.19-6.38 with it
+# (profiles/r03/ab_defer_lend.txt; an earlier form with a barrier through the origin stream: 6.16 -> 6.20, ab_defer_pool.txt) --
+# on paper the last bank runs alone for a quarter of the phase, in the replay every extra cross-stream wait costs more than it buys.
+wgrad_defer_pool = _os.environ.get("AST_WGRAD_DEFER_POOL", "0") != "0"
+wgrad_defer_lend = float(_os.environ.get("AST_WGRAD_DEFER_LEND", "1.0"))       # fraction of the helper's spare capacity that is used

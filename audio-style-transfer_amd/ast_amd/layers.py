@@ -41,6 +41,8 @@ class WeightBank:
         self._slab_recs = []          # (PackedWeight, pixel slices) of this backward pass's slab-mode weight gradients
         self._conv_deferred = []      # config.wgrad_defer: (dy, src, dwp, geometry, replicas, PackedWeight) launched by _flush
         self._defer_streams = []
+        self._pool_flushed = False    # _DeferPool: this bank's flush kernels were already launched (helper bank)
+        self._wait_lane = None        # _DeferPool: the helper's stream carries some of this bank's launches
         self.d_train = self.d_eval = None
         self._dev_consts = {}         # content -> device tensor (descriptor tables, tile lists): see _const_dev
         self._packed = {}             # (entry index, dtype, size) -> the entry's packed images and scratch
@@ -199,6 +201,13 @@ class WeightBank:
             slabs = (C.c_int32 * n)(*[sl for _, sl in part])
             check(lib().ast_slab_sum(bases, sizes, slabs, n, stream()), "ast_slab_sum")
 
+    def _flush_conv_kernels(self, side):
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if self._slab_recs:
+                self._sum_slabs()
+            check(lib().ast_weight_grads_flush_t(ptr(self.d_train), ptr(self.d_tiles), self.ntiles, stream()),
+                  "ast_weight_grads_flush_t")
+
     def _side_stream(self, origin):
         """This bank's flush stream, forked from `origin` once per parallel_flush() scope."""
         if self._flush_stream is None:
@@ -259,13 +268,16 @@ class WeightBank:
                 # the banks' flushes touch disjoint, persistent buffers (staging arena, masters, flat gradient): inside
                 # parallel_flush() each bank's pair of kernels runs on its own stream and the context joins them
                 side = self._side_stream(origin)
-            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                if self._conv_deferred:
-                    self._launch_deferred(origin)
-                if self._slab_recs:
-                    self._sum_slabs()
-                check(lib().ast_weight_grads_flush_t(ptr(self.d_train), ptr(self.d_tiles), self.ntiles, stream()),
-                      "ast_weight_grads_flush_t")
+            if self._pool_flushed:                  # _DeferPool already ran this bank's flush on its stream (it is the helper)
+                self._pool_flushed = False
+            else:
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                    if self._conv_deferred:
+                        self._launch_deferred(origin)
+                    if self._wait_lane is not None:     # launches of this bank that _DeferPool gave to the helper's stream
+                        torch.cuda.current_stream().wait_stream(self._wait_lane)
+                        self._wait_lane = None
+                self._flush_conv_kernels(side)
         if self._lin_deferred:
             items, self._lin_deferred = self._lin_deferred, []
             recs, max_tiles = [], 1
@@ -301,37 +313,48 @@ class _ParallelFlush:
 
 
 class _DeferPool:
-    """config.wgrad_defer_pool: the deferred weight gradients of ALL banks of a backward pass, longest first onto the least
-    loaded of the banks' flush streams (the banks differ in size: the last one used to run alone), launched by the first bank's
-    flush; the origin stream then waits for all of them and the banks' flush kernels follow it."""
+    """config.wgrad_defer_pool: balance the deferred weight gradients of a backward pass over the banks' flush streams.  The banks
+    differ in size (decoder < encoders) and the flush streams share the GPU unevenly, so the last bank used to run alone for a
+    quarter of the phase.  The SMALLEST bank's stream is the helper: it runs its own launches and its own flush, then takes over
+    the cheapest launches of the larger banks, whose flush streams wait for it -- waits in ONE direction only (the helper never
+    waits for a donor: mutual waits between side streams crash the capture, streams.py), no barrier through the origin."""
     banks = []
+    cost = staticmethod(lambda it: float(it[3].N) * it[3].Hm * it[3].Wm * max(it[3].Cd, 32) * max(it[3].ntaps * it[3].Cs, 64))
+
+    @staticmethod
+    def _run(lane, items):
+        for dy, src, dwp, g, replicas, pw in sorted(items, key=_DeferPool.cost, reverse=True):
+            dy.record_stream(lane)
+            src.record_stream(lane)
+            with torch.cuda.stream(lane):
+                ops._wgrad_launch(dy, src, dwp, g, replicas, pw)
 
     @staticmethod
     def launch_all(origin):
         banks, _DeferPool.banks = [b for b in _DeferPool.banks if b._conv_deferred], []
-        lanes = [b._side_stream(origin) for b in banks]
-        items = []
+        cost = _DeferPool.cost
+        tot = [sum(cost(it) for it in b._conv_deferred) for b in banks]
+        h = tot.index(min(tot))
+        target = sum(tot) / len(banks)
+        room = max(0.0, target - tot[h]) * config.wgrad_defer_lend
+        lent = []
         for bi, b in enumerate(banks):
-            items += [(bi, it) for it in b._conv_deferred]
+            keep = list(b._conv_deferred)
+            if bi != h and room > 0:
+                give = min(tot[bi] - target, room * (tot[bi] - target) / max(1e-9, sum(max(0.0, t - target) for i, t in enumerate(tot) if i != h)))
+                keep.sort(key=cost)                                   # cheapest first: the donor keeps (and starts with) its long launches
+                while keep and give >= cost(keep[0]):
+                    give -= cost(keep[0])
+                    lent.append(keep.pop(0))
+                if len(keep) < len(b._conv_deferred):
+                    b._wait_lane = banks[h]._side_stream(origin)
             b._conv_deferred = []
-        cost = lambda it: float(it[3].N) * it[3].Hm * it[3].Wm * max(it[3].Cd, 32) * max(it[3].ntaps * it[3].Cs, 64)
-        load = [0.0] * len(lanes)
-        for bi, it in sorted(items, key=lambda e: cost(e[1]), reverse=True):
-            i = load.index(min(load))
-            load[i] += cost(it)
-            dy, src, dwp, g, replicas, pw = it
-            dy.record_stream(lanes[i])
-            src.record_stream(lanes[i])
-            with torch.cuda.stream(lanes[i]):
-                ops._wgrad_launch(dy, src, dwp, g, replicas, pw)
-        # every bank's flush needs launches that ran on other banks' streams.  Mutual waits between the flush streams are the
-        # capture-crash shape of streams.py in its general form (A waits for B, then B waits for A: a stream waiting on a stream
-        # that already depends on it -- hipStreamEndCapture dumped core, gpurun_out/r3 run l), so the hand-over goes through the
-        # origin: it waits for all of them, they continue after it.
-        for st in lanes:
-            origin.wait_stream(st)
-        for st in lanes:
-            st.wait_stream(origin)
+            _DeferPool._run(b._side_stream(origin), keep)
+        helper = banks[h]
+        if lent:
+            helper._flush_conv_kernels(helper._side_stream(origin))   # the helper's own gradients are complete: flush, then help
+            helper._pool_flushed = True
+            _DeferPool._run(helper._side_stream(origin), lent)
 
 
 @contextlib.contextmanager
